@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- cavity-force evaluations per second on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE config 3 / 5 -- 1e6 molecular particles in neutral diatomics + the
+photon, finite-q start, g = 1e-3, omega_c = 2000 cm^-1 -- one independent replica per GPU (replica r has
+seed r + 1).  A "step" is one evaluation of the cavity force (three kernels) through the C ABI.  Successive
+steps walk a ring of `frames` trajectory frames (positions perturbed as the thermostatted integrator would),
+each with its own pos/charge/image/force arrays, sized so that the ring exceeds the 256 MiB Infinity Cache:
+every step streams its 92 N algorithmic bytes from HBM, as it would inside a real MD step whose other kernels
+have flushed the caches.  (The cache-hot figure, same frame every step, is reported under "extras".)
+
+All inputs are resident in HBM before the timed region.  Timing: W warm-up steps, barrier + synchronize,
+K steps, synchronize + barrier; the slowest rank's time is used; value = N_gpus * K / t.
+
+One JSON line on rank 0, with
+  roofline      dominant kernel's algorithmic bytes per launch / its mean launch duration (HIP events on the
+                launch stream, taken in a second pass of K steps so the events do not perturb `value`),
+                against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference's CavityForceCompute::computeForces, one thread) timed
+                on this box's host cores on the same workload for a bounded number of evaluations
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "cav-hoomd_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import cavitymd  # noqa: E402
+from cavitymd import replicas, synthetic  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable on copies)
+MALL_BYTES = 256 * 2**20
+BYTES_REDUCE = 52             # pos 32 + charge 8 + image 12   (dipole_partials_kernel)
+BYTES_MAP = 40                # charge 8 + force 32            (force_map_aos_kernel)
+BYTES_EVAL = BYTES_REDUCE + BYTES_MAP
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n-molecular", type=int, default=1_000_000)
+    ap.add_argument("--frames", type=int, default=0, help="trajectory frames in the ring (0 = enough to exceed 2x the Infinity Cache)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 1e5 / 1e7 / cache-hot side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class Frame:
+    """One trajectory frame resident on the GPU with its own compute object (force array + workspace)."""
+
+    def __init__(self, cfg, device):
+        pd = cavitymd.ParticleData.from_arrays(cfg["position"], cfg["typeid"], cfg["charge"], cfg["image"], cfg["types"],
+                                               cfg["box"], device=device)
+        p = cfg["params"]
+        self.compute = cavitymd.CavityForceComputeHIP(cavitymd.SystemDefinition(pd), p["omegac"], p["couplstr"],
+                                                      p["phmass"])
+        self.n = pd.getN()
+
+
+def build_ring(cfg, frames, device):
+    ring = [Frame(cfg, device)]
+    cur = cfg
+    for k in range(1, frames):
+        cur = synthetic.perturb(cur, k)
+        ring.append(Frame(cur, device))
+    return ring
+
+
+def run_steps(ring, steps, first=0):
+    nf = len(ring)
+    for s in range(first, first + steps):
+        ring[s % nf].compute.compute(s)
+
+
+def timed(ring, steps, warmup, ctx=None):
+    run_steps(ring, warmup)
+    if ctx is not None:
+        replicas.barrier(ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(ring, steps, first=warmup)
+    torch.cuda.synchronize()
+    if ctx is not None:
+        replicas.barrier(ctx)
+    return time.perf_counter() - t0
+
+
+def kernel_times(ring, steps, warmup):
+    """Mean device time per launch of each of the three kernels (HIP events on the launch stream)."""
+    for f in ring:
+        f.compute.workspace.profile_enable(True)
+    run_steps(ring, warmup)
+    for f in ring:
+        f.compute.workspace.profile_read()  # discard warm-up
+    run_steps(ring, steps, first=warmup)
+    tot = [0.0, 0.0, 0.0]
+    launches = 0
+    for f in ring:
+        ms, n = f.compute.workspace.profile_read()
+        tot = [a + b for a, b in zip(tot, ms)]
+        launches += n
+        f.compute.workspace.profile_enable(False)
+    return [t / max(launches, 1) for t in tot], launches
+
+
+def roofline_block(n, kt_ms):
+    names = ("dipole_partials_kernel", "finalize_kernel", "force_map_aos_kernel")
+    bytes_per_launch = (BYTES_REDUCE * n, 0, BYTES_MAP * n)
+    kernels = {}
+    for name, b, t in zip(names, bytes_per_launch, kt_ms):
+        kernels[name] = {"avg_ms": t, "algorithmic_bytes": b, "GBps": (b / (t * 1e-3) / 1e9) if t > 0 and b else None}
+    dom = 0 if kt_ms[0] >= kt_ms[2] else 2
+    achieved = bytes_per_launch[dom] / (kt_ms[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch[dom],
+            "avg_launch_ms": kt_ms[dom], "kernels": kernels,
+            "evaluation_GBps": BYTES_EVAL * n / (sum(kt_ms) * 1e-3) / 1e9}
+
+
+def load_pmc_traffic(workload_n):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), if they were taken
+    on this workload; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        ent = d.get(str(workload_n))
+        return ent
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(cfg, budget_s):
+    """The oracle (port of the reference CPU path) on one host thread, bounded sample of the same workload."""
+    import oracle
+    out = {}
+    pos4 = oracle.pack_pos(cfg["position"], cfg["typeid"])
+    for opt in ("O2", "O3"):
+        ref = oracle.RefOracle(opt)
+        p = ref.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+        args = (pos4, cfg["charge"], cfg["image"], cfg["box"], cfg["L_typeid"], p)
+        t1 = ref.time_evaluations(*args, 2) / 2          # warm-up + estimate
+        iters = int(max(3, min(2000, (budget_s / 2) / max(t1, 1e-9))))
+        t = ref.time_evaluations(*args, iters)
+        out[opt] = {"evals_per_s": iters / t, "iters": iters, "seconds": t}
+    best = "O2"
+    n = len(cfg["charge"])
+    return {"value": out[best]["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{out[best]['iters']} evaluations of frame 0 of the same workload (N={n}), oracle/cavity_ref.c "
+                      f"gcc -O2 -ffp-contract=off, 1 thread, {out[best]['seconds']:.1f} s",
+            "GBps_equiv": BYTES_EVAL * n * out[best]["evals_per_s"] / 1e9,
+            "O3_evals_per_s": out["O3"]["evals_per_s"], "host_cpus": os.cpu_count()}
+
+
+def side_measurement(cfg, device, frames, steps, warmup):
+    ring = build_ring(cfg, frames, device)
+    t = timed(ring, steps, warmup)
+    kt, _ = kernel_times(ring, steps, warmup)
+    n = ring[0].n
+    out = {"N": n, "frames": frames, "evals_per_s": steps / t, "us_per_eval": 1e6 * t / steps,
+           "evaluation_GBps_wall": BYTES_EVAL * n * steps / t / 1e9, "kernel_avg_us": [1e3 * x for x in kt],
+           "reduce_GBps": BYTES_REDUCE * n / (kt[0] * 1e-3) / 1e9, "map_GBps": BYTES_MAP * n / (kt[2] * 1e-3) / 1e9}
+    del ring
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse_args()
+    ctx = replicas.init_from_env(prefer_gpu=True)
+    if ctx.device.type != "cuda":
+        raise SystemExit("bench.py needs a GPU: the cavity force has no CPU path in this package")
+    if ctx.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world_size}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    frames = args.frames
+    if frames <= 0:
+        frames = max(2, math.ceil(2 * MALL_BYTES / (84 * (args.n_molecular + 1))))
+    p = synthetic.default_params()
+    spec = replicas.broadcast_spec(ctx, {
+        "omegac": p["omegac"], "couplstr": p["couplstr"], "phmass": p["phmass"], "n_molecular": args.n_molecular,
+        "base_seed": 0, "steps": args.steps, "warmup": args.warmup, "frames": frames, "finite_q": True,
+    } if ctx.rank == 0 else None)
+
+    # replica `rank + 1` of config 5 on this rank's GPU (seed = replica id)
+    replica_id = ctx.rank + 1
+    params = {"omegac": spec["omegac"], "couplstr": spec["couplstr"], "phmass": spec["phmass"]}
+    cfg = synthetic.diatomic_box(spec["n_molecular"], seed=replicas.replica_seed(replica_id, spec["base_seed"]),
+                                 finite_q=spec["finite_q"], image_range=1, params=params,
+                                 name=f"config5_replica{replica_id}")
+    ring = build_ring(cfg, spec["frames"], ctx.device)
+    n = ring[0].n
+    torch.cuda.synchronize()
+
+    elapsed = timed(ring, spec["steps"], spec["warmup"], ctx)
+    elapsed = replicas.max_over_ranks(ctx, elapsed)
+    value = ctx.world_size * spec["steps"] / elapsed
+
+    kt, launches = kernel_times(ring, spec["steps"], spec["warmup"])
+    roof = roofline_block(n, kt)
+    pmc = load_pmc_traffic(n)
+    if pmc is not None:
+        roof["traffic"] = pmc.get(roof["kernel"], {}).get("hbm_bytes_per_launch")
+        roof["traffic_detail"] = pmc
+
+    line = {
+        "metric": "cavity_force_evals_per_sec", "value": value, "unit": "evals/s", "n_gpus": ctx.world_size,
+        "steps": spec["steps"], "warmup": spec["warmup"], "ms_per_step": 1e3 * elapsed / spec["steps"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config3/config5: 1e6 diatomic particles + photon, finite-q start, g=1e-3, "
+                               "omegac=2000cm^-1; one independent replica per GPU (seed = rank+1); "
+                               f"ring of {spec['frames']} trajectory frames (HBM-cold)",
+                   "N_particles": n, "frames": spec["frames"], "replicas": ctx.world_size,
+                   "algorithmic_bytes_per_eval": BYTES_EVAL * n, "layout": "HOOMD AoS (Scalar4 pos/force, int3 image)",
+                   "collectives_on_data_path": 0},
+        "achieved_GBps_wall": BYTES_EVAL * n * value / 1e9,
+        "roofline": roof,
+    }
+
+    if ctx.rank == 0 and ctx.world_size == 1:
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        if not args.no_extras:
+            del ring
+            torch.cuda.empty_cache()
+            extras = {}
+            extras["1e6_cache_hot"] = side_measurement(cfg, ctx.device, 1, spec["steps"], spec["warmup"])
+            extras["1e5_cache_hot"] = side_measurement(synthetic.config2(), ctx.device, 1, 300, 30)
+            extras["1e5_ring"] = side_measurement(synthetic.config2(), ctx.device, 64, 300, 30)
+            extras["1e7_hbm"] = side_measurement(synthetic.config4(), ctx.device, 2, 50, 5)
+            line["extras"] = extras
+    if ctx.rank == 0:
+        print(json.dumps(line), flush=True)
+    replicas.shutdown(ctx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,560 @@
+// cavmd_capi.hip -- implementation of include/cavmd.h on top of the kernels in cavmd_kernels.hpp.
+//
+// Host side of the replaced reference code: CavityForceComputeGPU::computeForces
+// (src/CavityForceComputeGPU.cc:102-253) and kernel::gpu_compute_cavity_force
+// (src/CavityForceComputeGPU.cu:507-617).  Where the reference does 4 memsets, 1 H2D and 2 blocking
+// D2H copies, a device synchronise and a host scan of the position array per step, this enqueues
+// three kernels on the caller's stream and returns; energies are fetched lazily by cavmd_energies.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "cavmd.h"
+#include "cavmd_kernels.hpp"
+
+using namespace cavmd;
+
+namespace
+{
+constexpr int kReduceBlock = 256;
+constexpr int kReduceUnroll = 4;
+constexpr int kFinalizeBlock = 256;
+constexpr int kMapBlock = 256;
+constexpr int kMapUnroll = 4;
+constexpr int kMaxBlocksPerCU = 16;
+constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
+
+static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
+static_assert(sizeof(cavmd_int3) == 12, "int3 layout");
+static_assert(sizeof(cavmd_params) == 32, "params layout");
+static_assert(sizeof(cavmd_result) == 192, "result layout");
+} // namespace
+
+struct cavmd_workspace
+{
+    int device = -1;
+    int num_cu = 0;
+    char arch[64] = {0};
+    size_t max_N = 0;
+    unsigned max_parts = 0;
+    double* d_part = nullptr;
+    int* d_ipart = nullptr;
+    cavmd_result* d_result = nullptr;
+    cavmd_result* h_result = nullptr; // pinned
+    hipStream_t last_stream = nullptr;
+    bool computed = false;
+    uint64_t sequence = 0;
+    // tunables
+    int reduce_blocks_per_cu = 8;
+    int map_blocks_per_cu = 8;
+    int map_nt_store = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events; // 4 per slot
+    int pending = 0;
+    double acc_ms[3] = {0, 0, 0};
+    uint64_t acc_launches = 0;
+};
+
+namespace
+{
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev)
+        {
+            switched = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+};
+
+inline int hip_status(hipError_t e)
+{
+    return e == hipSuccess ? CAVMD_OK : (int)e;
+}
+
+#define CAVMD_HIP_TRY(expr)              \
+    do                                   \
+    {                                    \
+        hipError_t _e = (expr);          \
+        if (_e != hipSuccess)            \
+            return (int)_e;              \
+    } while (0)
+
+bool params_ok(const cavmd_params* p)
+{
+    return p && isfinite(p->omegac) && isfinite(p->couplstr) && isfinite(p->K) && isfinite(p->phmass) && p->K != 0.0;
+}
+
+int drain_profile(cavmd_workspace* ws)
+{
+    // all pending events were recorded on streams the caller has used; wait for the last of each slot
+    for (int s = 0; s < ws->pending; ++s)
+    {
+        hipEvent_t* ev = &ws->events[4 * s];
+        CAVMD_HIP_TRY(hipEventSynchronize(ev[3]));
+        for (int k = 0; k < 3; ++k)
+        {
+            float ms = 0.f;
+            CAVMD_HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            ws->acc_ms[k] += (double)ms;
+        }
+        ws->acc_launches += 1;
+    }
+    ws->pending = 0;
+    return CAVMD_OK;
+}
+
+unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_cu)
+{
+    size_t tiles = (work_items + tile - 1) / tile;
+    size_t cap = (size_t)num_cu * (size_t)blocks_per_cu;
+    size_t g = tiles < cap ? tiles : cap;
+    return (unsigned)(g ? g : 1);
+}
+
+// Enqueue finalize + the event bookkeeping shared by both layouts.
+struct EventScope
+{
+    cavmd_workspace* ws;
+    hipStream_t stream;
+    hipEvent_t* ev = nullptr;
+    int status = CAVMD_OK;
+    EventScope(cavmd_workspace* w, hipStream_t s) : ws(w), stream(s)
+    {
+        if (!ws->profiling)
+            return;
+        if (ws->pending == kProfileSlots)
+            status = drain_profile(ws);
+        if (status == CAVMD_OK)
+            ev = &ws->events[4 * ws->pending];
+    }
+    int mark(int k)
+    {
+        if (!ev)
+            return CAVMD_OK;
+        return hip_status(hipEventRecord(ev[k], stream));
+    }
+    void commit()
+    {
+        if (ev)
+            ws->pending += 1;
+    }
+};
+} // namespace
+
+extern "C"
+{
+
+cavmd_params cavmd_make_params(double omegac, double couplstr, double phmass)
+{
+    cavmd_params p;
+    p.omegac = omegac;
+    p.couplstr = couplstr;
+    p.phmass = phmass;
+    p.K = phmass * omegac * omegac; // src/CavityForceCompute.h:41, evaluated left to right
+    return p;
+}
+
+int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
+{
+    if (!out_ws)
+        return CAVMD_ERR_INVALID_VALUE;
+    *out_ws = nullptr;
+    if (max_N > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY; // indices travel as int32 (photon_idx), as in the reference
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return CAVMD_ERR_NO_DEVICE;
+    if (device < 0)
+    {
+        if (hipGetDevice(&device) != hipSuccess)
+            return CAVMD_ERR_NO_DEVICE;
+    }
+    if (device >= count)
+        return CAVMD_ERR_INVALID_VALUE;
+
+    cavmd_workspace* ws = new (std::nothrow) cavmd_workspace();
+    if (!ws)
+        return (int)hipErrorOutOfMemory;
+    ws->device = device;
+    ws->max_N = max_N;
+    DeviceGuard guard(device);
+
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+    {
+        delete ws;
+        return (int)e;
+    }
+    ws->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    strncpy(ws->arch, prop.gcnArchName, sizeof(ws->arch) - 1);
+    ws->max_parts = (unsigned)(ws->num_cu * kMaxBlocksPerCU);
+
+    e = hipMalloc((void**)&ws->d_part, sizeof(double) * kNumPartDoubles * ws->max_parts);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&ws->d_ipart, sizeof(int) * kNumPartInts * ws->max_parts);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&ws->d_result, sizeof(cavmd_result));
+    if (e == hipSuccess)
+        e = hipMemset(ws->d_result, 0, sizeof(cavmd_result));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&ws->h_result, sizeof(cavmd_result), hipHostMallocDefault);
+    if (e != hipSuccess)
+    {
+        cavmd_destroy(ws);
+        return (int)e;
+    }
+    memset(ws->h_result, 0, sizeof(cavmd_result));
+    *out_ws = ws;
+    return CAVMD_OK;
+}
+
+int cavmd_destroy(cavmd_workspace* ws)
+{
+    if (!ws)
+        return CAVMD_OK;
+    DeviceGuard guard(ws->device);
+    for (hipEvent_t ev : ws->events)
+        (void)hipEventDestroy(ev);
+    if (ws->d_part)
+        (void)hipFree(ws->d_part);
+    if (ws->d_ipart)
+        (void)hipFree(ws->d_ipart);
+    if (ws->d_result)
+        (void)hipFree(ws->d_result);
+    if (ws->h_result)
+        (void)hipHostFree(ws->h_result);
+    delete ws;
+    return CAVMD_OK;
+}
+
+int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavmd_double4* d_pos, const double* d_charge,
+                        const cavmd_int3* d_image, double Lx, double Ly, double Lz, int L_typeid,
+                        const cavmd_params* params, cavmd_double4* d_force)
+{
+    // argument validation first, as kernel::gpu_compute_cavity_force does (src/CavityForceComputeGPU.cu:522-532)
+    if (!ws || !d_pos || !d_charge || !d_image || !d_force || !params)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (((uintptr_t)d_pos & 15) || ((uintptr_t)d_force & 15) || ((uintptr_t)d_charge & 7) || ((uintptr_t)d_image & 3))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (N == 0)
+        return CAVMD_OK;
+    if (N > ws->max_N)
+        return CAVMD_ERR_CAPACITY;
+    if (!params_ok(params))
+        return CAVMD_ERR_BAD_PARAMS;
+
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    EventScope evs(ws, stream);
+    if (evs.status != CAVMD_OK)
+        return evs.status;
+
+    AosInput in;
+    in.pos2 = reinterpret_cast<const v2d*>(d_pos);
+    in.charge = d_charge;
+    in.image = reinterpret_cast<const int*>(d_image);
+    Partials part {ws->d_part, ws->d_ipart, ws->max_parts};
+    const unsigned n = (unsigned)N;
+
+    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    int st;
+    if ((st = evs.mark(0)) != CAVMD_OK)
+        return st;
+    hipLaunchKernelGGL((dipole_partials_kernel<AosInput, kReduceBlock, kReduceUnroll>), dim3(g1), dim3(kReduceBlock), 0,
+                       stream, in, n, Lx, Ly, Lz, L_typeid, part);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(1)) != CAVMD_OK)
+        return st;
+
+    ws->sequence += 1;
+    hipLaunchKernelGGL((finalize_kernel<AosInput, kFinalizeBlock>), dim3(1), dim3(kFinalizeBlock), 0, stream, in, n, g1,
+                       Lx, Ly, Lz, *params, part, ws->sequence, ws->d_result);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(2)) != CAVMD_OK)
+        return st;
+
+    const unsigned g2 = grid_for(2 * N, kMapBlock * kMapUnroll, ws->num_cu, ws->map_blocks_per_cu);
+    v2d* force2 = reinterpret_cast<v2d*>(d_force);
+    if (ws->map_nt_store)
+        hipLaunchKernelGGL((force_map_aos_kernel<kMapBlock, kMapUnroll, true>), dim3(g2), dim3(kMapBlock), 0, stream,
+                           d_charge, in.pos2, n, params->couplstr, L_typeid, ws->d_result, force2);
+    else
+        hipLaunchKernelGGL((force_map_aos_kernel<kMapBlock, kMapUnroll, false>), dim3(g2), dim3(kMapBlock), 0, stream,
+                           d_charge, in.pos2, n, params->couplstr, L_typeid, ws->d_result, force2);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(3)) != CAVMD_OK)
+        return st;
+    evs.commit();
+
+    ws->last_stream = stream;
+    ws->computed = true;
+    return CAVMD_OK;
+}
+
+int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double* d_position, size_t position_stride,
+                      const int32_t* d_typeid, size_t typeid_stride, const int32_t* d_image, size_t image_stride,
+                      const double* d_charge, size_t charge_stride, double Lx, double Ly, double Lz, int L_typeid,
+                      const cavmd_params* params, double* d_force, size_t force_stride, double* d_potential_energy,
+                      size_t potential_energy_stride)
+{
+    if (!ws || !d_position || !d_typeid || !d_image || !d_charge || !d_force || !params)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (position_stride < 24 || typeid_stride < 4 || image_stride < 12 || charge_stride < 8 || force_stride < 24
+        || (d_potential_energy && potential_energy_stride < 8))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (((uintptr_t)d_position & 7) || (position_stride & 7) || ((uintptr_t)d_charge & 7) || (charge_stride & 7)
+        || ((uintptr_t)d_force & 7) || (force_stride & 7) || ((uintptr_t)d_typeid & 3) || (typeid_stride & 3)
+        || ((uintptr_t)d_image & 3) || (image_stride & 3)
+        || (d_potential_energy && (((uintptr_t)d_potential_energy & 7) || (potential_energy_stride & 7))))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (N == 0)
+        return CAVMD_OK;
+    if (N > ws->max_N)
+        return CAVMD_ERR_CAPACITY;
+    if (!params_ok(params))
+        return CAVMD_ERR_BAD_PARAMS;
+
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    EventScope evs(ws, stream);
+    if (evs.status != CAVMD_OK)
+        return evs.status;
+
+    StridedInput in;
+    in.pos = reinterpret_cast<const char*>(d_position);
+    in.tid = reinterpret_cast<const char*>(d_typeid);
+    in.img = reinterpret_cast<const char*>(d_image);
+    in.chg = reinterpret_cast<const char*>(d_charge);
+    in.pos_stride = position_stride;
+    in.tid_stride = typeid_stride;
+    in.img_stride = image_stride;
+    in.chg_stride = charge_stride;
+    Partials part {ws->d_part, ws->d_ipart, ws->max_parts};
+    const unsigned n = (unsigned)N;
+
+    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    int st;
+    if ((st = evs.mark(0)) != CAVMD_OK)
+        return st;
+    hipLaunchKernelGGL((dipole_partials_kernel<StridedInput, kReduceBlock, kReduceUnroll>), dim3(g1), dim3(kReduceBlock),
+                       0, stream, in, n, Lx, Ly, Lz, L_typeid, part);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(1)) != CAVMD_OK)
+        return st;
+
+    ws->sequence += 1;
+    hipLaunchKernelGGL((finalize_kernel<StridedInput, kFinalizeBlock>), dim3(1), dim3(kFinalizeBlock), 0, stream, in, n,
+                       g1, Lx, Ly, Lz, *params, part, ws->sequence, ws->d_result);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(2)) != CAVMD_OK)
+        return st;
+
+    const unsigned g2 = grid_for(N, kMapBlock, ws->num_cu, ws->map_blocks_per_cu);
+    hipLaunchKernelGGL((force_map_strided_kernel<kMapBlock>), dim3(g2), dim3(kMapBlock), 0, stream, in, n,
+                       params->couplstr, L_typeid, ws->d_result, reinterpret_cast<char*>(d_force), force_stride,
+                       reinterpret_cast<char*>(d_potential_energy), potential_energy_stride);
+    CAVMD_HIP_TRY(hipGetLastError());
+    if ((st = evs.mark(3)) != CAVMD_OK)
+        return st;
+    evs.commit();
+
+    ws->last_stream = stream;
+    ws->computed = true;
+    return CAVMD_OK;
+}
+
+int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
+{
+    if (!ws || !out)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!ws->computed)
+        return CAVMD_ERR_NOT_COMPUTED;
+    DeviceGuard guard(ws->device);
+    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_result, ws->d_result, sizeof(cavmd_result), hipMemcpyDeviceToHost, ws->last_stream));
+    CAVMD_HIP_TRY(hipStreamSynchronize(ws->last_stream));
+    memcpy(out, ws->h_result, sizeof(cavmd_result));
+    return CAVMD_OK;
+}
+
+int cavmd_energies(cavmd_workspace* ws, double out[3])
+{
+    if (!ws || !out)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!ws->computed)
+    {
+        // the reference's getters return the 0.0 its constructor stored (src/CavityForceCompute.cc:33-36)
+        out[0] = out[1] = out[2] = 0.0;
+        return CAVMD_OK;
+    }
+    cavmd_result r;
+    int st = cavmd_result_read(ws, &r);
+    if (st != CAVMD_OK)
+        return st;
+    out[0] = r.energy[0];
+    out[1] = r.energy[1];
+    out[2] = r.energy[2];
+    return CAVMD_OK;
+}
+
+int cavmd_result_device_ptr(cavmd_workspace* ws, const cavmd_result** out)
+{
+    if (!ws || !out)
+        return CAVMD_ERR_INVALID_VALUE;
+    *out = ws->d_result;
+    return CAVMD_OK;
+}
+
+int cavmd_profile_enable(cavmd_workspace* ws, int on)
+{
+    if (!ws)
+        return CAVMD_ERR_INVALID_VALUE;
+    DeviceGuard guard(ws->device);
+    if (on && ws->events.empty())
+    {
+        ws->events.resize(4 * kProfileSlots);
+        for (size_t i = 0; i < ws->events.size(); ++i)
+        {
+            hipError_t e = hipEventCreate(&ws->events[i]);
+            if (e != hipSuccess)
+            {
+                for (size_t j = 0; j < i; ++j)
+                    (void)hipEventDestroy(ws->events[j]);
+                ws->events.clear();
+                return (int)e;
+            }
+        }
+    }
+    if (!on && ws->pending)
+    {
+        int st = drain_profile(ws);
+        if (st != CAVMD_OK)
+            return st;
+    }
+    ws->profiling = on != 0;
+    return CAVMD_OK;
+}
+
+int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* launches)
+{
+    if (!ws || !ms || !launches)
+        return CAVMD_ERR_INVALID_VALUE;
+    DeviceGuard guard(ws->device);
+    int st = drain_profile(ws);
+    if (st != CAVMD_OK)
+        return st;
+    for (int k = 0; k < 3; ++k)
+    {
+        ms[k] = ws->acc_ms[k];
+        ws->acc_ms[k] = 0.0;
+    }
+    *launches = ws->acc_launches;
+    ws->acc_launches = 0;
+    return CAVMD_OK;
+}
+
+int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
+{
+    if (!ws || !name)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!strcmp(name, "reduce_blocks_per_cu"))
+    {
+        if (value < 1 || value > kMaxBlocksPerCU)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->reduce_blocks_per_cu = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "map_blocks_per_cu"))
+    {
+        if (value < 1 || value > kMaxBlocksPerCU)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->map_blocks_per_cu = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "map_nt_store"))
+    {
+        if (value != 0 && value != 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->map_nt_store = value;
+        return CAVMD_OK;
+    }
+    return CAVMD_ERR_INVALID_VALUE;
+}
+
+int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
+{
+    if (!ws || !name || !value)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!strcmp(name, "reduce_blocks_per_cu"))
+        *value = ws->reduce_blocks_per_cu;
+    else if (!strcmp(name, "map_blocks_per_cu"))
+        *value = ws->map_blocks_per_cu;
+    else if (!strcmp(name, "map_nt_store"))
+        *value = ws->map_nt_store;
+    else
+        return CAVMD_ERR_INVALID_VALUE;
+    return CAVMD_OK;
+}
+
+int cavmd_device_info(cavmd_workspace* ws, int* device, int* compute_units, char* arch_name, size_t arch_name_len)
+{
+    if (!ws)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (device)
+        *device = ws->device;
+    if (compute_units)
+        *compute_units = ws->num_cu;
+    if (arch_name && arch_name_len)
+    {
+        strncpy(arch_name, ws->arch, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return CAVMD_OK;
+}
+
+const char* cavmd_error_string(int status)
+{
+    switch (status)
+    {
+    case CAVMD_OK:
+        return "success";
+    case CAVMD_ERR_INVALID_VALUE:
+        return "invalid value (null or misaligned pointer, bad stride or size)";
+    case CAVMD_ERR_NO_DEVICE:
+        return "no HIP device available (this library has no CPU fallback)";
+    case CAVMD_ERR_CAPACITY:
+        return "N exceeds the workspace capacity";
+    case CAVMD_ERR_BAD_PARAMS:
+        return "bad cavity parameters (K == 0 or non-finite)";
+    case CAVMD_ERR_NOT_COMPUTED:
+        return "no evaluation has been enqueued on this workspace yet";
+    default:
+        break;
+    }
+    if (status > 0)
+        return hipGetErrorString((hipError_t)status);
+    return "unknown cavmd status";
+}
+
+int cavmd_version(void)
+{
+    return CAVMD_VERSION_MAJOR * 1000 + CAVMD_VERSION_MINOR;
+}
+
+} // extern "C"

@@ -1,0 +1,204 @@
+/* cavmd.h -- C ABI of the MI355X (gfx950) cavity-MD force engine.
+ *
+ * This is the drop-in boundary for ONE hot path of muhammadhasyim/cav-hoomd: the per-step
+ * cavity force evaluation.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   reference                                              this library
+ *   ----------------------------------------------------   ---------------------------------
+ *   struct cavity_force_params  src/CavityForceCompute.h:28-54      cavmd_params / cavmd_make_params
+ *   CavityForceComputeGPU ctor (scratch GPUArrays)
+ *                               src/CavityForceComputeGPU.cc:31-93  cavmd_create / cavmd_destroy
+ *   kernel::gpu_compute_cavity_force(...)
+ *                               src/CavityForceComputeGPU.cuh:28-40 cavmd_compute_hoomd
+ *   CavityForcePython.set_forces (snapshot-layout arrays)
+ *                               src/cavitymd/cavity_force_python.py:65-145
+ *                                                                   cavmd_compute_soa
+ *   getHarmonicEnergy/getCouplingEnergy/getDipoleSelfEnergy
+ *                               src/CavityForceCompute.cc:58-71     cavmd_energies
+ *   CavityForceCompute::computeForces (the CPU semantics both follow)
+ *                               src/CavityForceCompute.cc:134-208   (semantic contract, see below)
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch/HOOMD types cross this boundary.
+ *   - every function returns an int status: CAVMD_OK (0), a CAVMD_ERR_* code (< 0), or a positive
+ *     hipError_t forwarded from the HIP runtime.  Nothing throws across the ABI.
+ *   - all particle buffers are DEVICE pointers owned by the caller (HOOMD's GlobalArrays, a torch
+ *     tensor, ...).  The library owns only its workspace.  No allocation, no host synchronisation
+ *     and no host<->device copy happens inside cavmd_compute_*; they only enqueue kernels on
+ *     `stream` (NULL = the null stream, which is what HOOMD-blue 4.x uses), so a caller may
+ *     capture them into a hipGraph.
+ *   - Scalar = double (HOOMD's default HOOMD_LONGREAL_SIZE=64 build).
+ *
+ * Semantic contract (what "the same result as the reference" means here; file:line = reference)
+ *   photon      = first index i whose type tag equals L_typeid (src/CavityForceCompute.cc:73-89);
+ *                 the tag is the low 32 bits of the bit pattern of pos[i].w (HOOMD __scalar_as_int).
+ *   r_i         = pos_i + image_i * (Lx,Ly,Lz), orthorhombic lengths only (:91-111).
+ *   d           = sum_{i != photon} charge_i * r_i  (:113-129).  The reference sums left to right;
+ *                 this library uses a fixed-shape compensated tree, so d agrees to ~1 ulp with the
+ *                 exactly rounded sum, and is bit-reproducible from run to run.
+ *   E_h = 1/2 K (q.q) with the 3-D q;  E_c = g (d_xy . q_xy);  E_d = 1/2 (g^2/K)(d_xy . d_xy) (:174-176)
+ *   F_i = (-g c_i Dq_x, -g c_i Dq_y, 0, 0) for every particle whose type is not L,
+ *         Dq = q_xy + (g/K) d_xy (:183-200);  L-typed particles other than the photon get 0.
+ *   F_L = (-K q_x - g d_x, -K q_y - g d_y, -K q_z, 0) (:203-207).
+ *   no particle of type L -> all forces 0, all energies 0, not an error (:148-156).
+ *   virial / torque are never written (the reference leaves them zero).
+ */
+#ifndef CAVMD_H_
+#define CAVMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define CAVMD_API
+#else
+#define CAVMD_API __attribute__((visibility("default")))
+#endif
+
+#define CAVMD_VERSION_MAJOR 0
+#define CAVMD_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define CAVMD_OK 0
+#define CAVMD_ERR_INVALID_VALUE (-1) /* null pointer / bad size; mirrors hipErrorInvalidValue at
+                                        src/CavityForceComputeGPU.cu:522-528 */
+#define CAVMD_ERR_NO_DEVICE (-2)     /* no HIP device visible: the product path never falls back to a CPU */
+#define CAVMD_ERR_CAPACITY (-3)      /* N exceeds the capacity the workspace was created for */
+#define CAVMD_ERR_BAD_PARAMS (-4)    /* K == 0 or non-finite parameters */
+#define CAVMD_ERR_NOT_COMPUTED (-5)  /* results requested before any cavmd_compute_* call */
+
+/* ---- layouts (bit-compatible with HOOMD-blue's Scalar4 / int3 in a double-precision build) -- */
+typedef struct cavmd_double4
+{
+    double x, y, z, w;
+} cavmd_double4; /* 32 B; pos.w carries the type id in its low 32 bits, force.w is the per-particle PE */
+
+typedef struct cavmd_int3
+{
+    int32_t x, y, z;
+} cavmd_int3; /* 12 B, packed */
+
+/* One POD parameter block shared by host, device and this ABI (the reference defines it twice with
+ * different alignment: src/CavityForceCompute.h:28-54 and src/CavityForceComputeGPU.cu:24-30). */
+typedef struct cavmd_params
+{
+    double omegac;   /* cavity frequency, atomic units */
+    double couplstr; /* coupling strength g, atomic units */
+    double K;        /* spring constant = phmass * omegac^2 */
+    double phmass;   /* photon mass */
+} cavmd_params;
+
+/* Everything one evaluation produces besides the per-particle forces (192 B, lives in the workspace
+ * on the device; cavmd_result_read copies it out). */
+typedef struct cavmd_result
+{
+    double dipole[3];        /* molecular dipole d (photon excluded), all three components */
+    double q[3];             /* unwrapped photon position */
+    double Dq[2];            /* q_xy + (g/K) d_xy */
+    double energy[3];        /* harmonic, coupling, dipole-self */
+    double photon_force[3];  /* F_L */
+    double dipole_lo[3];     /* low words of the compensated dipole sum (diagnostic) */
+    int32_t photon_idx;      /* index of the photon, -1 if there is none */
+    int32_t n_photon_typed;  /* how many particles carry type L (the driver enforces exactly 1) */
+    uint32_t n_particles;    /* N of the evaluation this result belongs to */
+    uint32_t n_partials;     /* partial sums that fed the final reduction (diagnostic) */
+    uint64_t sequence;       /* evaluation counter of the workspace */
+    double reserved[4];
+} cavmd_result;
+
+typedef struct cavmd_workspace cavmd_workspace; /* opaque */
+
+/* ---- parameters ----------------------------------------------------------------------------- */
+/* K = phmass * omegac^2, as cavity_force_params(omegac, couplstr, phmass) at src/CavityForceCompute.h:38-42 */
+CAVMD_API cavmd_params cavmd_make_params(double omegac, double couplstr, double phmass);
+
+/* ---- life cycle ----------------------------------------------------------------------------- */
+/* Binds a workspace to HIP device `device` (-1 = the current device) sized for up to max_N particles.
+ * Replaces the four scratch GPUArrays of CavityForceComputeGPU (src/CavityForceComputeGPU.cc:43-54);
+ * unlike them the partial-sum buffer is sized from the launch geometry, never from a constant. */
+CAVMD_API int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws);
+CAVMD_API int cavmd_destroy(cavmd_workspace* ws);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* HOOMD-native AoS layouts.  Replaces kernel::gpu_compute_cavity_force
+ * (src/CavityForceComputeGPU.cuh:28-40): d_force/d_pos/d_charge/d_image keep their meaning, `box`
+ * becomes the three orthorhombic lengths box.getL() returns, the four scratch pointers become `ws`.
+ * N == 0 is a success that touches nothing (src/CavityForceComputeGPU.cu:530-532).
+ * Writes all N entries of d_force (x, y, z and w): no separate memset pass is needed or performed. */
+CAVMD_API int cavmd_compute_hoomd(cavmd_workspace* ws,
+                                  void* stream,
+                                  size_t N,
+                                  const cavmd_double4* d_pos,
+                                  const double* d_charge,
+                                  const cavmd_int3* d_image,
+                                  double Lx,
+                                  double Ly,
+                                  double Lz,
+                                  int L_typeid,
+                                  const cavmd_params* params,
+                                  cavmd_double4* d_force);
+
+/* Snapshot ("local snapshot") layouts used by the hoomd.md.force.Custom surface
+ * (src/cavitymd/cavity_force_python.py:72-145): position (N,3) f64, typeid (N,) i32, image (N,3) i32,
+ * charge (N,) f64 -> force (N,3) f64 and, if not NULL, potential_energy (N,) f64 (set to 0, as the
+ * reference does at :126-131).  Strides are in BYTES between consecutive particles, so the same
+ * entry point serves packed arrays (24, 4, 12, 8, 24, 8) and HOOMD's strided views of its Scalar4
+ * buffers (32, 32, 12, 8, 32, 32).  Same semantics as cavmd_compute_hoomd (the C++ ones: photon =
+ * first particle of type L_typeid, photon excluded from d, L-typed particles get no molecular force). */
+CAVMD_API int cavmd_compute_soa(cavmd_workspace* ws,
+                                void* stream,
+                                size_t N,
+                                const double* d_position,
+                                size_t position_stride,
+                                const int32_t* d_typeid,
+                                size_t typeid_stride,
+                                const int32_t* d_image,
+                                size_t image_stride,
+                                const double* d_charge,
+                                size_t charge_stride,
+                                double Lx,
+                                double Ly,
+                                double Lz,
+                                int L_typeid,
+                                const cavmd_params* params,
+                                double* d_force,
+                                size_t force_stride,
+                                double* d_potential_energy,
+                                size_t potential_energy_stride);
+
+/* ---- results -------------------------------------------------------------------------------- */
+/* The three energy getters of src/CavityForceCompute.cc:58-71 in one call:
+ * out[0] = harmonic, out[1] = coupling, out[2] = dipole self-energy.  Lazy: enqueues a 192-byte
+ * device->pinned-host copy behind the last evaluation on its stream and waits for it. */
+CAVMD_API int cavmd_energies(cavmd_workspace* ws, double out[3]);
+/* Whole result block (dipole, photon position and force, photon index, ...). */
+CAVMD_API int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out);
+/* Device address of the result block, for consumers that stay on the GPU (trackers, graphs). */
+CAVMD_API int cavmd_result_device_ptr(cavmd_workspace* ws, const cavmd_result** out);
+
+/* ---- measurement hooks (bench.py's roofline leg) ---------------------------------------------- */
+/* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */
+CAVMD_API int cavmd_profile_enable(cavmd_workspace* ws, int on);
+/* Synchronises and returns the accumulated device time per kernel since the last reset:
+ * ms[0] = dipole partial-sum kernel, ms[1] = finalize kernel, ms[2] = force-map kernel;
+ * *launches = evaluations accumulated.  Resets the accumulators. */
+CAVMD_API int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* launches);
+
+/* ---- tuning / introspection ------------------------------------------------------------------- */
+/* Launch geometry knobs; name is one of "reduce_blocks_per_cu", "map_blocks_per_cu", "map_nt_store".
+ * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value. */
+CAVMD_API int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value);
+CAVMD_API int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value);
+CAVMD_API int cavmd_device_info(cavmd_workspace* ws, int* device, int* compute_units, char* arch_name, size_t arch_name_len);
+CAVMD_API const char* cavmd_error_string(int status);
+CAVMD_API int cavmd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAVMD_H_ */

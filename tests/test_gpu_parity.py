@@ -1,0 +1,468 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.  Run with `-m gpu` on an MI355X.
+
+Tolerances (stated here as the contract):
+  P1 dipole         |d_gpu - d_ref|_inf <= 1e-10 * |d_ref|_inf       (ref = sequential fp64 sum, the reference order)
+  P2 energies       each of E_h, E_c, E_d: relative <= 1e-10          (never only their sum: it cancels at finite q)
+  P3 forces         |F_gpu - F_ref| <= 1e-10 * S_i,  S_i = g|c_i|(|q_xy|_inf + (g/K)|d_xy|_inf) for molecules,
+                    S_L = K|q|_inf + g|d_xy|_inf for the photon (the scale before the cancellation in Dq)
+  P4 accuracy       |F_gpu - F_exact| <= |F_ref - F_exact| + 1e-14 * S_i   (exact = correctly rounded dipole)
+  P5 structure      F.z == 0 and F.w == 0 exactly for molecules, every entry written, no-photon -> all zeros,
+                    bit-identical results from run to run
+The GPU dipole itself is additionally required to be within 2 ulp of the correctly rounded sum.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cavitymd
+from cavitymd import _capi, synthetic
+from oracle import numpy_mirror as nm
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+# ---- helpers ---------------------------------------------------------------------------------------------------
+def to_device(cfg, device="cuda"):
+    pd = cavitymd.ParticleData.from_arrays(cfg["position"], cfg["typeid"], cfg["charge"], cfg["image"], cfg["types"],
+                                           cfg["box"], device=device)
+    return cavitymd.SystemDefinition(pd)
+
+
+def gpu_eval(cfg, tunables=None):
+    sysdef = to_device(cfg)
+    p = cfg["params"]
+    comp = cavitymd.CavityForceComputeHIP(sysdef, p["omegac"], p["couplstr"], p["phmass"])
+    for k, v in (tunables or {}).items():
+        comp.workspace.set_tunable(k, v)
+    comp.getForceArray().fill_(float("nan"))  # every entry must be overwritten
+    comp.compute(0)
+    torch.cuda.synchronize()
+    res = comp.getResult()
+    return {"force": comp.getForceArray().cpu().numpy(), "energies": np.array(comp.getEnergies()),
+            "dipole": np.array(res.dipole[:]), "dipole_lo": np.array(res.dipole_lo[:]), "photon_idx": res.photon_idx,
+            "n_L": res.n_photon_typed, "q": np.array(res.q[:]), "Dq": np.array(res.Dq[:]), "result": res, "comp": comp}
+
+
+def ref_eval(ref, oracle_mod, cfg):
+    p = ref.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+    pos4 = oracle_mod.pack_pos(cfg["position"], cfg["typeid"])
+    out = ref.compute(pos4, cfg["charge"], cfg["image"], cfg["box"], cfg["L_typeid"], p)
+    out["params"] = p
+    out["pos4"] = pos4
+    if out["photon_idx"] >= 0:
+        hi, lo = ref.dipole_exact(pos4, cfg["charge"], cfg["image"], cfg["box"], out["photon_idx"])
+        out["dipole_exact"] = hi
+    return out
+
+
+def force_scales(cfg, refout):
+    p = refout["params"]
+    g, K = p["couplstr"], p["K"]
+    pidx = refout["photon_idx"]
+    box = np.asarray(cfg["box"])
+    q = cfg["position"][pidx] + cfg["image"][pidx] * box
+    d = refout["dipole"]
+    s_mol = g * np.abs(cfg["charge"]) * (np.abs(q[:2]).max() + (g / K) * np.abs(d[:2]).max())
+    s_L = K * np.abs(q).max() + g * np.abs(d[:2]).max()
+    S = s_mol.copy()
+    S[pidx] = s_L
+    return S
+
+
+def forces_from_dipole(cfg, refout, d):
+    """Forces the reference formulas give for a prescribed dipole (used with the exactly rounded one)."""
+    p = refout["params"]
+    g, K = p["couplstr"], p["K"]
+    pidx = refout["photon_idx"]
+    box = np.asarray(cfg["box"])
+    q = cfg["position"][pidx] + cfg["image"][pidx] * box
+    Dq = np.array([q[0] + (g / K) * d[0], q[1] + (g / K) * d[1]])
+    F = np.zeros((len(cfg["charge"]), 4))
+    s = (-g) * cfg["charge"]
+    F[:, 0] = s * Dq[0]
+    F[:, 1] = s * Dq[1]
+    F[cfg["typeid"] == cfg["L_typeid"]] = 0.0
+    F[pidx, :3] = [-K * q[0] - g * d[0], -K * q[1] - g * d[1], -K * q[2] - g * 0.0]
+    return F
+
+
+def check_parity(cfg, gpu, refout, tol=1e-10):
+    assert gpu["photon_idx"] == refout["photon_idx"]
+    assert not np.isnan(gpu["force"]).any(), "force entries left unwritten"
+    if refout["photon_idx"] < 0:
+        assert not gpu["force"].any() and not gpu["energies"].any()
+        return {}
+    d_ref, d_gpu, d_exact = refout["dipole"], gpu["dipole"], refout["dipole_exact"]
+    # P1
+    assert np.abs(d_gpu - d_ref).max() <= tol * np.abs(d_ref).max() + 1e-300
+    # GPU dipole is the correctly rounded sum to within 2 ulp
+    assert np.all(np.abs(d_gpu - d_exact) <= 2 * np.spacing(np.abs(d_exact)) + 1e-300)
+    # P2
+    for k in range(3):
+        e_ref, e_gpu = refout["energies"][k], gpu["energies"][k]
+        assert abs(e_gpu - e_ref) <= tol * abs(e_ref) + 1e-300, ("energy", k, e_gpu, e_ref)
+    # P3
+    S = force_scales(cfg, refout)
+    diff = np.abs(gpu["force"][:, :3] - refout["force"][:, :3])
+    assert np.all(diff <= tol * S[:, None] + 1e-300), float((diff / (S[:, None] + 1e-300)).max())
+    # P4
+    F_exact = forces_from_dipole(cfg, refout, d_exact)
+    err_gpu = np.abs(gpu["force"][:, :3] - F_exact[:, :3])
+    err_ref = np.abs(refout["force"][:, :3] - F_exact[:, :3])
+    assert np.all(err_gpu <= err_ref + 1e-14 * S[:, None] + 1e-300)
+    # P5
+    mol = np.ones(len(S), dtype=bool)
+    mol[refout["photon_idx"]] = False
+    assert np.all(gpu["force"][mol, 2] == 0.0) and np.all(gpu["force"][:, 3] == 0.0)
+    raw_rel = diff[mol, :2] / (np.abs(refout["force"][mol, :2]) + 1e-300)
+    return {"max_scaled_force_err": float((diff / (S[:, None] + 1e-300)).max()),
+            "max_raw_rel_force_err": float(raw_rel.max()) if raw_rel.size else 0.0,
+            "dipole_rel_err_vs_ref": float(np.abs(d_gpu - d_ref).max() / np.abs(d_ref).max())}
+
+
+# ---- known answers and golden vectors ----------------------------------------------------------------------------
+def test_known_answers_bit_exact(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "kat_golden.json")))
+    for case in kat["cases"]:
+        cfg = {"position": np.array(case["position"], dtype=float), "typeid": np.array(case["typeid"], dtype=np.int32),
+               "charge": np.array(case["charge"], dtype=float), "image": np.array(case["image"], dtype=np.int32),
+               "types": ["A", "B", "C"], "box": tuple(case["box"]), "L_typeid": case["L_typeid"],
+               "params": {"omegac": case["omegac"], "couplstr": case["couplstr"], "phmass": case["phmass"]}}
+        cfg["types"][case["L_typeid"]] = "L"
+        out = gpu_eval(cfg)
+        assert out["photon_idx"] == case["photon_idx"], case["name"]
+        assert np.array_equal(out["force"], np.array(case["force"], dtype=float)), case["name"]
+        assert np.array_equal(out["energies"], np.array(case["energies"], dtype=float)), case["name"]
+        assert np.array_equal(out["dipole"], np.array(case["dipole"], dtype=float)), case["name"]
+
+
+def test_config1_against_committed_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "config1_oracle.npz"))
+    cfg = synthetic.config1(seed=1)
+    out = gpu_eval(cfg)
+    assert out["photon_idx"] == 500 == int(g["photon_idx"])
+    assert np.all(np.abs(out["dipole"] - g["dipole_exact_hi"]) <= 2 * np.spacing(np.abs(g["dipole_exact_hi"])))
+    assert np.allclose(out["energies"], g["energies"], rtol=1e-12, atol=0)
+    scale = np.abs(g["force"]).max()
+    assert np.abs(out["force"] - g["force"]).max() <= 1e-12 * scale
+
+
+def test_config1_thousand_step_pseudo_trajectory(ref, oracle_mod):
+    """BASELINE config 1: '1k steps' on the init-0.gsd stand-in.  HOOMD integration is impossible here, so the
+    positions follow a fixed pseudo-trajectory (r += 1e-3 N(0,1) per step) and GPU and oracle are compared at
+    every step, reusing ONE compute object (workspace, force array) as a simulation would."""
+    cfg = synthetic.config1(seed=1)
+    sysdef = to_device(cfg)
+    pd = sysdef.getParticleData()
+    p = cfg["params"]
+    comp = cavitymd.CavityForceComputeHIP(sysdef, p["omegac"], p["couplstr"], p["phmass"])
+    worst = 0.0
+    for step in range(1000):
+        if step:
+            cfg = synthetic.perturb(cfg, step)
+            pos4 = oracle_mod.pack_pos(cfg["position"], cfg["typeid"])
+            pd.getPositions().copy_(torch.from_numpy(pos4))
+            pd.getImages().copy_(torch.from_numpy(cfg["image"]))
+        comp.compute(step)
+        gpu = {"force": comp.getForceArray().cpu().numpy(), "energies": np.array(comp.getEnergies())}
+        res = comp.getResult()
+        gpu.update(dipole=np.array(res.dipole[:]), photon_idx=res.photon_idx)
+        assert res.sequence == step + 1
+        stats = check_parity(cfg, gpu, ref_eval(ref, oracle_mod, cfg))
+        worst = max(worst, stats["max_scaled_force_err"])
+    assert worst <= 1e-10
+
+
+# ---- the BASELINE sizes -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("maker,kwargs", [(synthetic.config2, {}), (synthetic.config3, {}), (synthetic.config4, {})],
+                         ids=["config2_1e5", "config3_1e6_finite_q", "config4_1e7"])
+def test_full_size_parity_and_properties(ref, oracle_mod, maker, kwargs):
+    cfg = maker(**kwargs)
+    n = len(cfg["charge"])
+    gpu = gpu_eval(cfg)
+    refout = ref_eval(ref, oracle_mod, cfg)
+    stats = check_parity(cfg, gpu, refout)
+    print(f"\n{cfg['name']}: N={n} {stats}")
+    comp = gpu["comp"]
+    # determinism: same bits on a second and third evaluation
+    for _ in range(2):
+        comp.compute(1)
+        torch.cuda.synchronize()
+        assert np.array_equal(comp.getForceArray().cpu().numpy(), gpu["force"])
+        assert np.array_equal(np.array(comp.getResult().dipole[:]), gpu["dipole"])
+    # exact linearity: doubling every charge doubles every addend exactly, so d doubles bit for bit
+    pd = comp._pdata
+    pd.getCharges().mul_(2.0)
+    comp.compute(2)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.array(comp.getResult().dipole[:]), 2.0 * gpu["dipole"])
+    pd.getCharges().mul_(0.5)
+    # sum rule: sum_i F_i,xy over molecules = -g Q_tot Dq  (Q_tot ~ 0 for neutral systems -> compare absolutely)
+    g = cfg["params"]["couplstr"]
+    mol = np.ones(n, dtype=bool)
+    mol[gpu["photon_idx"]] = False
+    lhs = gpu["force"][mol, :2].sum(axis=0)
+    rhs = -g * cfg["charge"][mol].sum() * gpu["Dq"]
+    assert np.all(np.abs(lhs - rhs) <= 1e-9 * g * np.abs(cfg["charge"]).sum() * np.abs(gpu["Dq"]).max() + 1e-300)
+    # image shift: moving every molecule one box length along x changes d_x by Q_tot * Lx
+    pd.getImages()[:-1, 0] += 1
+    comp.compute(3)
+    torch.cuda.synchronize()
+    d_shift = np.array(comp.getResult().dipole[:])
+    term_scale = np.abs(cfg["charge"]).sum() * (cfg["box"][0] * 3)
+    assert abs((d_shift[0] - gpu["dipole"][0]) - cfg["charge"][mol].sum() * cfg["box"][0]) <= 1e-12 * term_scale
+    assert d_shift[1] == gpu["dipole"][1] and d_shift[2] == gpu["dipole"][2]
+
+
+# ---- edge cases -------------------------------------------------------------------------------------------------------------
+def _random_cfg(n, seed, photon_at=None, L=(31.0, 17.5, 23.25), image_range=3, photon_charge=0.0):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-0.5, 0.5, (n, 3)) * np.asarray(L)
+    tid = rng.integers(0, 2, n).astype(np.int32)
+    charge = rng.uniform(-1, 1, n)
+    if photon_at is not None:
+        tid[photon_at] = 2
+        charge[photon_at] = photon_charge
+    image = rng.integers(-image_range, image_range + 1, (n, 3)).astype(np.int32)
+    return {"name": f"rand{n}", "seed": seed, "position": pos, "typeid": tid, "charge": charge, "image": image,
+            "types": ["O", "N", "L"], "box": L, "L_typeid": 2,
+            "params": {"omegac": 0.0091, "couplstr": 1e-3, "phmass": 1.0}}
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049,
+                               4095, 4097, 10_000, 65_537, 262_145, 300_001])
+def test_ragged_sizes_and_photon_positions(ref, oracle_mod, n):
+    """Every tile-boundary neighbourhood of both kernels, and the sizes where the reference's own GPU path breaks
+    (N > 65 536 partial-sum truncation, N > 100 000 early-out, N > 262 144 buffer overrun)."""
+    for photon_at in sorted({0, n // 2, n - 1}):
+        cfg = _random_cfg(n, seed=n * 7 + photon_at, photon_at=photon_at)
+        check_parity(cfg, gpu_eval(cfg), ref_eval(ref, oracle_mod, cfg))
+
+
+def test_no_photon_zeroes_everything(ref, oracle_mod):
+    for n in (1, 777, 5000):
+        cfg = _random_cfg(n, seed=n)
+        out = gpu_eval(cfg)
+        assert out["photon_idx"] == -1 and not out["force"].any() and not out["energies"].any()
+        assert not out["dipole"].any()
+    # no type named 'L' at all: the compute passes -1 (reference GPU class: energies zero, src/CavityForceComputeGPU.cc:114-123)
+    cfg = _random_cfg(100, seed=1, photon_at=5)
+    cfg["types"] = ["O", "N", "X"]
+    out = gpu_eval(cfg)
+    assert out["photon_idx"] == -1 and not out["force"].any()
+
+
+def test_charged_photon_is_excluded_from_dipole(ref, oracle_mod):
+    cfg = _random_cfg(3000, seed=3, photon_at=1234, photon_charge=7.5)
+    check_parity(cfg, gpu_eval(cfg), ref_eval(ref, oracle_mod, cfg))
+
+
+def test_several_L_typed_particles(ref, oracle_mod):
+    """Degenerate input: only the FIRST 'L' is the photon; later ones enter the dipole but get no force
+    (src/CavityForceCompute.cc:122 vs :191).  The reference's GPU kernel gets this wrong (Appendix A.4)."""
+    cfg = _random_cfg(5000, seed=9, photon_at=100)
+    for extra in (0, 99, 101, 2500, 4999):
+        if extra != 100:
+            cfg["typeid"][extra] = 2
+    cfg["typeid"][0] = 0  # photon is index 99? no: first L is 99
+    gpu = gpu_eval(cfg)
+    refout = ref_eval(ref, oracle_mod, cfg)
+    assert gpu["photon_idx"] == refout["photon_idx"] == 99
+    assert gpu["n_L"] == 5
+    # the L-sum detour costs one extra rounding: compare at 1e-12 of the scale instead of the 2-ulp dipole test
+    assert np.abs(gpu["dipole"] - refout["dipole"]).max() <= 1e-12 * np.abs(refout["dipole"]).max()
+    S = force_scales(cfg, refout)
+    assert np.all(np.abs(gpu["force"][:, :3] - refout["force"][:, :3]) <= 1e-10 * S[:, None] + 1e-300)
+    for i in (101, 2500, 4999):
+        assert not gpu["force"][i].any()
+
+
+def test_large_images_and_garbage_type_high_word(ref, oracle_mod):
+    cfg = _random_cfg(4000, seed=21, photon_at=3999, image_range=1 << 20)
+    check_parity(cfg, gpu_eval(cfg), ref_eval(ref, oracle_mod, cfg))
+    # HOOMD's __int_as_scalar leaves the high word of pos.w unspecified: only the low 32 bits are the type
+    sysdef = to_device(cfg)
+    pd = sysdef.getParticleData()
+    w = pd.getPositions()[:, 3].view(torch.int64)
+    w |= (0x5EADBEEF << 32)
+    comp = cavitymd.CavityForceComputeHIP(sysdef, 0.0091, 1e-3, 1.0)
+    comp.compute(0)
+    assert comp.getResult().photon_idx == 3999
+
+
+def test_tunables_do_not_change_the_physics(ref, oracle_mod):
+    cfg = _random_cfg(200_003, seed=5, photon_at=200_002)
+    base = gpu_eval(cfg)
+    refout = ref_eval(ref, oracle_mod, cfg)
+    check_parity(cfg, base, refout)
+    for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
+                {"map_blocks_per_cu": 16, "map_nt_store": 1}):
+        out = gpu_eval(cfg, tun)
+        check_parity(cfg, out, refout)
+        assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))
+
+
+# ---- the ABI itself ----------------------------------------------------------------------------------------------------------
+def test_abi_argument_validation():
+    lib = _capi.load()
+    ws = _capi.Workspace(1000)
+    n = 1000
+    pos = torch.zeros(n, 4, dtype=torch.float64, device="cuda")
+    chg = torch.zeros(n, dtype=torch.float64, device="cuda")
+    img = torch.zeros(n, 3, dtype=torch.int32, device="cuda")
+    frc = torch.full((n, 4), 7.0, dtype=torch.float64, device="cuda")
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+
+    def call(N, pos_p, chg_p, img_p, frc_p, params):
+        return lib.cavmd_compute_hoomd(ws.handle, None, N, pos_p, chg_p, img_p, 10.0, 10.0, 10.0, 2,
+                                       ctypes.byref(params) if params is not None else None, frc_p)
+
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert call(n, None, P(chg), P(img), P(frc), prm) == _capi.CAVMD_ERR_INVALID_VALUE
+    assert call(n, P(pos), P(chg), P(img), None, prm) == _capi.CAVMD_ERR_INVALID_VALUE
+    assert call(n, P(pos), P(chg), P(img), P(frc), None) == _capi.CAVMD_ERR_INVALID_VALUE
+    assert call(n, ctypes.c_void_p(pos.data_ptr() + 8), P(chg), P(img), P(frc), prm) == _capi.CAVMD_ERR_INVALID_VALUE
+    assert call(n + 1, P(pos), P(chg), P(img), P(frc), prm) == _capi.CAVMD_ERR_CAPACITY
+    bad = _capi.make_params(0.0, 1e-3, 1.0)  # K == 0
+    assert call(n, P(pos), P(chg), P(img), P(frc), bad) == _capi.CAVMD_ERR_BAD_PARAMS
+    # N == 0 succeeds and touches nothing (src/CavityForceComputeGPU.cu:530-532)
+    assert call(0, P(pos), P(chg), P(img), P(frc), prm) == 0
+    torch.cuda.synchronize()
+    assert torch.all(frc == 7.0)
+    # energies before any evaluation read 0.0 like the reference's freshly constructed compute
+    assert ws.energies() == (0.0, 0.0, 0.0)
+    with pytest.raises(_capi.CavmdError):
+        ws.result()
+    info = ws.device_info()
+    assert info["arch"].startswith("gfx950") and info["compute_units"] == 256
+    with pytest.raises(_capi.CavmdError):
+        ws.set_tunable("reduce_blocks_per_cu", 0)
+    with pytest.raises(_capi.CavmdError):
+        ws.set_tunable("nonsense", 1)
+
+
+def test_side_stream_and_result_device_pointer(ref, oracle_mod):
+    cfg = _random_cfg(50_000, seed=8, photon_at=49_999)
+    sysdef = to_device(cfg)
+    comp = cavitymd.CavityForceComputeHIP(sysdef, 0.0091, 1e-3, 1.0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    comp.compute(0, stream=side)
+    e = comp.getEnergies()  # syncs `side`, not the device
+    refout = ref_eval(ref, oracle_mod, cfg)
+    assert np.allclose(e, refout["energies"], rtol=1e-10, atol=0)
+    assert comp.workspace.result_device_ptr() != 0
+
+
+def test_graph_capture_and_replay(ref, oracle_mod):
+    """cavmd_compute_* only enqueues kernels, so it can be captured into a hipGraph and replayed on new data."""
+    cfg = _random_cfg(30_000, seed=12, photon_at=29_999)
+    sysdef = to_device(cfg)
+    pd = sysdef.getParticleData()
+    comp = cavitymd.CavityForceComputeHIP(sysdef, 0.0091, 1e-3, 1.0)
+    comp.compute(0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        comp.compute(1)
+    cfg2 = synthetic.perturb(cfg, 1, amplitude=0.5)
+    pd.getPositions().copy_(torch.from_numpy(oracle_mod.pack_pos(cfg2["position"], cfg2["typeid"])))
+    pd.getImages().copy_(torch.from_numpy(cfg2["image"]))
+    comp.getForceArray().fill_(float("nan"))
+    graph.replay()
+    torch.cuda.synchronize()
+    gpu = {"force": comp.getForceArray().cpu().numpy(), "energies": np.array(comp.getEnergies())}
+    res = comp.getResult()
+    gpu.update(dipole=np.array(res.dipole[:]), photon_idx=res.photon_idx)
+    check_parity(cfg2, gpu, ref_eval(ref, oracle_mod, cfg2))
+
+
+# ---- the snapshot-layout entry point (hoomd.md.force.Custom surface) -----------------------------------------------------------
+def _soa_eval(cfg, hoomd_views, with_pe=True):
+    n = len(cfg["charge"])
+    prm = _capi.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+    ws = _capi.Workspace(n)
+    dev = "cuda"
+    chg = torch.from_numpy(cfg["charge"]).to(dev)
+    img = torch.from_numpy(cfg["image"]).to(dev)
+    if hoomd_views:
+        # HOOMD's local snapshot hands out strided views of its Scalar4 buffers: position = pos[:, :3] (stride 32),
+        # typeid = int view of pos.w (stride 32), force = force4[:, :3] (stride 32), potential_energy = force4[:, 3]
+        pos4 = torch.from_numpy(np.ascontiguousarray(
+            np.concatenate([cfg["position"], cavitymd.state.type_tag_as_double(cfg["typeid"])[:, None]], axis=1))).to(dev)
+        frc4 = torch.full((n, 4), float("nan"), dtype=torch.float64, device=dev)
+        position, typeid = (pos4.data_ptr(), 32), (pos4.data_ptr() + 24, 32)
+        force, pe = (frc4.data_ptr(), 32), (frc4.data_ptr() + 24, 32)
+        keep = (pos4, frc4)
+    else:
+        pos3 = torch.from_numpy(np.ascontiguousarray(cfg["position"])).to(dev)
+        tid = torch.from_numpy(cfg["typeid"].astype(np.int32)).to(dev)
+        frc3 = torch.full((n, 3), float("nan"), dtype=torch.float64, device=dev)
+        pe1 = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+        position, typeid = (pos3.data_ptr(), 24), (tid.data_ptr(), 4)
+        force, pe = (frc3.data_ptr(), 24), (pe1.data_ptr(), 8)
+        keep = (pos3, tid, frc3, pe1)
+    ws.compute_soa(0, n, position, typeid, (img.data_ptr(), 12), (chg.data_ptr(), 8), cfg["box"], cfg["L_typeid"], prm,
+                   force, pe if with_pe else None)
+    torch.cuda.synchronize()
+    res = ws.result()
+    if hoomd_views:
+        f4 = keep[1].cpu().numpy()
+    else:
+        f4 = np.concatenate([keep[2].cpu().numpy(), keep[3].cpu().numpy()[:, None]], axis=1)
+    if not with_pe:
+        assert np.isnan(f4[:, 3]).all()
+        f4[:, 3] = 0.0
+    return {"force": f4, "energies": np.array(ws.energies()), "dipole": np.array(res.dipole[:]),
+            "photon_idx": res.photon_idx}
+
+
+@pytest.mark.parametrize("hoomd_views", [False, True], ids=["packed", "hoomd_strided_views"])
+def test_snapshot_layout_entry_point(ref, oracle_mod, hoomd_views):
+    for n, photon_at in ((1, 0), (1025, 7), (70_001, 70_000)):
+        cfg = _random_cfg(n, seed=n + 3, photon_at=photon_at)
+        check_parity(cfg, _soa_eval(cfg, hoomd_views), ref_eval(ref, oracle_mod, cfg))
+    cfg = _random_cfg(999, seed=2)  # no photon
+    out = _soa_eval(cfg, hoomd_views)
+    assert out["photon_idx"] == -1 and not out["force"].any()
+    cfg = _random_cfg(5000, seed=4, photon_at=4000)
+    check_parity(cfg, _soa_eval(cfg, hoomd_views, with_pe=False), ref_eval(ref, oracle_mod, cfg))
+
+
+def test_both_layouts_give_identical_bits():
+    cfg = _random_cfg(123_457, seed=77, photon_at=123_456)
+    a = gpu_eval(cfg)
+    b = _soa_eval(cfg, hoomd_views=False)
+    assert np.array_equal(a["dipole"], b["dipole"]) and np.array_equal(a["energies"], b["energies"])
+    assert np.array_equal(a["force"], b["force"])
+
+
+# ---- the user-facing object ---------------------------------------------------------------------------------------------------
+def test_cavity_force_object_end_to_end(ref, oracle_mod):
+    cfg = synthetic.config1(seed=3)
+    p = cfg["params"]
+    f = cavitymd.CavityForce(kvector=[0, 0, 1], couplstr=p["couplstr"], omegac=p["omegac"], phmass=p["phmass"])
+    f.attach(to_device(cfg))
+    f.compute(0)
+    refout = ref_eval(ref, oracle_mod, cfg)
+    assert f.implementation == "hip"
+    assert f.harmonic_energy == pytest.approx(refout["energies"][0], rel=1e-10)
+    assert f.coupling_energy == pytest.approx(refout["energies"][1], rel=1e-10)
+    assert f.dipole_self_energy == pytest.approx(refout["energies"][2], rel=1e-10)
+    assert f.total_cavity_energy == f.harmonic_energy + f.coupling_energy + f.dipole_self_energy == f.energy
+    assert f.forces.shape == (501, 3)
+    S = force_scales(cfg, refout)
+    assert np.all(np.abs(f.forces - refout["force"][:, :3]) <= 1e-10 * S[:, None])
+    # setParams at run time (src/CavityForceCompute.cc:48-51)
+    f._force_impl.setParams(p["omegac"], 2 * p["couplstr"], p["phmass"])
+    assert f._force_impl.getParams()["couplstr"] == 2 * p["couplstr"]
+    f.compute(1)
+    assert f.coupling_energy == pytest.approx(2 * refout["energies"][1], rel=1e-10)
+    f.detach()
+    assert f.energy == 0.0

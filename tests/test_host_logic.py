@@ -1,0 +1,121 @@
+"""Host-side logic that needs no GPU: the Python surface mirrored from the reference, the particle-data
+stand-in, unit constants, synthetic configurations, replica planning."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cavitymd
+from cavitymd import replicas, synthetic
+from cavitymd.state import type_tag_as_double
+
+
+def test_package_exports_reference_names():
+    # src/cavitymd/__init__.py:6-13 of the reference exports these for the force path
+    for name in ("CavityForce", "PhysicalConstants", "unwrap_positions"):
+        assert hasattr(cavitymd, name)
+
+
+def test_constants_and_conversions_match_reference_utils(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "utils_golden.json")))
+    PC = cavitymd.PhysicalConstants
+    for k, v in g["constants"].items():
+        assert getattr(PC, k) == v, k
+    for t, v in g["conversions"]["ps_to_atomic_units"]:
+        assert PC.ps_to_atomic_units(t) == v
+    for t, v in g["conversions"]["atomic_units_to_ps"]:
+        assert PC.atomic_units_to_ps(t) == v
+    for t, v in g["conversions"]["gamma_from_tau_ps"]:
+        assert PC.gamma_from_tau_ps(t) == v
+    with pytest.raises(ValueError):
+        PC.gamma_from_tau_ps(0.0)
+    assert PC.omegac_from_wavenumber(2000.0) == g["omegac_2000cm"]
+    for case in g["unwrap_cases"]:
+        got = cavitymd.unwrap_positions(np.array(case["positions"]), np.array(case["images"]), np.array(case["box"]))
+        assert np.array_equal(got, np.array(case["unwrapped"]))
+
+
+def test_cavity_force_surface():
+    f = cavitymd.CavityForce(kvector=[0, 0, 1], couplstr=1e-3, omegac=0.00911267, phmass=1.0)
+    assert np.array_equal(f.kvector, np.array([0.0, 0.0, 1.0]))
+    assert (f.couplstr, f.omegac, f.phmass) == (1e-3, 0.00911267, 1.0)
+    # before attach every loggable reads 0.0, as the reference's `if self._force_impl else 0.0` (forces.py:183-198)
+    assert f.harmonic_energy == 0.0 and f.coupling_energy == 0.0 and f.dipole_self_energy == 0.0
+    assert f.total_cavity_energy == 0.0 and f.energy == 0.0
+    assert f.forces is None and f.set_forces(0) is None
+    with pytest.raises(RuntimeError):
+        f.compute(0)
+    with pytest.raises(ValueError):
+        cavitymd.CavityForce(kvector=[0, 1], couplstr=1e-3, omegac=0.1)
+
+
+def test_particle_data_accessors():
+    cfg = synthetic.config1()
+    pd = cavitymd.ParticleData.from_arrays(cfg["position"], cfg["typeid"], cfg["charge"], cfg["image"], cfg["types"],
+                                           cfg["box"], device="cpu")
+    assert pd.getN() == 501
+    assert pd.getTypeByName("L") == 2 and pd.getTypeByName("O") == 0
+    with pytest.raises(RuntimeError, match="Type X not found"):
+        pd.getTypeByName("X")
+    assert pd.getGlobalBox().getL() == (40.0, 40.0, 40.0)
+    pos = pd.getPositions().numpy()
+    # the type id sits in the low 32 bits of pos.w
+    tags = (pos[:, 3].view(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.array_equal(tags, cfg["typeid"])
+    assert type_tag_as_double(np.array([-1])).view(np.uint64)[0] == 0xFFFFFFFF
+    with pytest.raises(ValueError):
+        cavitymd.ParticleData(torch.zeros(3, 3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64),
+                              torch.zeros(3, 3, dtype=torch.int32), ["A"], (1, 1, 1))
+
+
+def test_synthetic_configs_follow_the_schema():
+    c1 = synthetic.config1()
+    assert c1["position"].shape == (501, 3) and c1["types"] == ["O", "N", "L"]
+    L = c1["box"][0]
+    assert np.all(c1["position"] >= -L / 2) and np.all(c1["position"] < L / 2)
+    assert abs(c1["charge"][:-1].sum()) < 1e-12          # neutral molecules
+    assert set(np.unique(c1["image"][:-1])) <= {-2, -1, 0, 1, 2}
+    # bond lengths survive the wrap: O-O 2.2817, N-N 2.0744 bohr
+    r = c1["position"] + c1["image"] * np.asarray(c1["box"])[None, :]
+    bonds = np.linalg.norm(r[0:500:2] - r[1:500:2], axis=1)
+    assert np.allclose(bonds[0::2], synthetic.BOND_OO) and np.allclose(bonds[1::2], synthetic.BOND_NN)
+    c2 = synthetic.config2(n_molecular=2000)
+    assert c2["position"].shape == (2001, 3) and abs(c2["charge"].sum()) < 1e-9
+    assert np.array_equal(c2["typeid"][:-1], np.arange(2000) % 2) and c2["typeid"][-1] == 2
+    # finite-q: photon sits near -d g / omegac^2 (z about 0), examples/05_advanced_run.py:464-471
+    c3 = synthetic.config3(n_molecular=2000)
+    r3 = c3["position"] + c3["image"] * np.asarray(c3["box"])[None, :]
+    d = (c3["charge"][:-1, None] * r3[:-1]).sum(axis=0)
+    p = c3["params"]
+    sigma = np.sqrt(cavitymd.PhysicalConstants.KB_HARTREE_PER_K * 100.0 / p["omegac"]**2)
+    target = -d * p["couplstr"] / p["omegac"]**2
+    assert abs(r3[-1, 0] - target[0]) < 6 * sigma and abs(r3[-1, 1] - target[1]) < 6 * sigma and abs(r3[-1, 2]) < 6 * sigma
+    # replicas differ only by seed
+    a, b = synthetic.config5_replica(0, 200), synthetic.config5_replica(1, 200)
+    assert a["seed"] == 1 and b["seed"] == 2 and not np.array_equal(a["position"], b["position"])
+    # pseudo-trajectory keeps particles wrapped and moves them a little
+    s = synthetic.perturb(c1, 7)
+    r1 = s["position"] + s["image"] * np.asarray(s["box"])[None, :]
+    assert np.all(s["position"] >= -L / 2) and np.all(s["position"] < L / 2)
+    assert 0 < np.abs(r1 - r).max() < 1e-2
+
+
+def test_replica_planning():
+    assert replicas.parse_replicas("1-8") == [1, 2, 3, 4, 5, 6, 7, 8]
+    assert replicas.parse_replicas("3,1, 1-2,7") == [1, 2, 3, 7]
+    assert replicas.parse_replicas("") == [1] and replicas.parse_replicas(None) == [1]
+    plan = replicas.assign_replicas(range(1, 9), 4)
+    assert plan == [[1, 5], [2, 6], [3, 7], [4, 8]]
+    assert sorted(sum(replicas.assign_replicas([1, 2, 3], 8), [])) == [1, 2, 3]
+    assert [replicas.replica_seed(r) for r in range(1, 9)] == list(range(1, 9))
+    spec = {"omegac": 0.0091, "couplstr": 1e-3, "phmass": 1.0, "n_molecular": 1_000_000, "base_seed": 0, "steps": 50,
+            "warmup": 5, "frames": 7, "finite_q": True}
+    back = replicas.unpack_block(replicas.pack_block(spec))
+    for k, v in spec.items():
+        assert back[k] == v
+    bad = replicas.pack_block(spec)
+    bad[9] = 99.0
+    with pytest.raises(RuntimeError, match="version"):
+        replicas.unpack_block(bad)
