@@ -6,6 +6,7 @@
 // D2H copies, a device synchronise and a host scan of the position array per step, this enqueues
 // three kernels on the caller's stream and returns; energies are fetched lazily by cavmd_energies.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -27,7 +28,9 @@ constexpr int kFinalizeBlock = 256;
 constexpr int kMapBlock = 256;
 constexpr int kMapUnroll = 4;
 constexpr int kMaxBlocksPerCU = 16;
+constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
+constexpr size_t kChargeTemporalMaxN = (size_t)1 << 21; // 16 MiB of charges
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
 static_assert(sizeof(cavmd_int3) == 12, "int3 layout");
@@ -50,13 +53,18 @@ struct cavmd_workspace
     bool computed = false;
     uint64_t sequence = 0;
     // tunables
-    int reduce_blocks_per_cu = 8;
-    int map_blocks_per_cu = 8;
+    // Defaults from interleaved A/B runs on MI355X (csrc/microbench.hip; profiles/r01/microbench_*.txt):
+    int reduce_blocks_per_cu = 1; // <= 256 partials: the fused force map folds them with one load per thread
+    int map_blocks_per_cu = 2;    // every fused block re-folds the partials, so few, long-lived blocks
     int map_nt_store = 0;
+    int reduce_nt_load = -1;      // -1 auto, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
+    int reduce_pipeline = 0;      // 1: double-buffered tiles (measured: no gain, 194 VGPRs)
+    int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     // profiling
     bool profiling = false;
-    std::vector<hipEvent_t> events; // 4 per slot
+    std::vector<hipEvent_t> events; // kEventsPerSlot per slot: start/stop of each of the three kernels
     int pending = 0;
+    std::vector<unsigned> slot_mask; // which of the three kernels a slot's evaluation launched
     double acc_ms[3] = {0, 0, 0};
     uint64_t acc_launches = 0;
 };
@@ -101,15 +109,17 @@ bool params_ok(const cavmd_params* p)
 
 int drain_profile(cavmd_workspace* ws)
 {
-    // all pending events were recorded on streams the caller has used; wait for the last of each slot
     for (int s = 0; s < ws->pending; ++s)
     {
-        hipEvent_t* ev = &ws->events[4 * s];
-        CAVMD_HIP_TRY(hipEventSynchronize(ev[3]));
+        hipEvent_t* ev = &ws->events[kEventsPerSlot * s];
+        const unsigned used = ws->slot_mask[s];
         for (int k = 0; k < 3; ++k)
         {
+            if (!(used & (1u << k)))
+                continue;
+            CAVMD_HIP_TRY(hipEventSynchronize(ev[2 * k + 1]));
             float ms = 0.f;
-            CAVMD_HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            CAVMD_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
             ws->acc_ms[k] += (double)ms;
         }
         ws->acc_launches += 1;
@@ -126,32 +136,44 @@ unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_c
     return (unsigned)(g ? g : 1);
 }
 
-// Enqueue finalize + the event bookkeeping shared by both layouts.
-struct EventScope
+// Per-kernel timing for bench.py's roofline leg.  When profiling is on, every kernel is launched through
+// hipExtLaunchKernelGGL with its own start/stop events: those take the dispatch packet's begin/end timestamps (what
+// rocprofv3 --kernel-trace reports), unlike hipEventRecord markers between kernels, which add ~2.5 us each.
+struct LaunchScope
 {
     cavmd_workspace* ws;
     hipStream_t stream;
     hipEvent_t* ev = nullptr;
+    unsigned used = 0;
     int status = CAVMD_OK;
-    EventScope(cavmd_workspace* w, hipStream_t s) : ws(w), stream(s)
+    LaunchScope(cavmd_workspace* w, hipStream_t s) : ws(w), stream(s)
     {
         if (!ws->profiling)
             return;
         if (ws->pending == kProfileSlots)
             status = drain_profile(ws);
         if (status == CAVMD_OK)
-            ev = &ws->events[4 * ws->pending];
+            ev = &ws->events[kEventsPerSlot * ws->pending];
     }
-    int mark(int k)
+    template <class K, class... Args>
+    int launch(int slot, K kernel, unsigned grid, unsigned block, Args... args)
     {
-        if (!ev)
-            return CAVMD_OK;
-        return hip_status(hipEventRecord(ev[k], stream));
+        if (ev)
+        {
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, ev[2 * slot], ev[2 * slot + 1], 0, args...);
+            used |= 1u << slot;
+        }
+        else
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args...);
+        return hip_status(hipGetLastError());
     }
     void commit()
     {
         if (ev)
+        {
+            ws->slot_mask[ws->pending] = used;
             ws->pending += 1;
+        }
     }
 };
 } // namespace
@@ -262,9 +284,9 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    EventScope evs(ws, stream);
-    if (evs.status != CAVMD_OK)
-        return evs.status;
+    LaunchScope ls(ws, stream);
+    if (ls.status != CAVMD_OK)
+        return ls.status;
 
     AosInput in;
     in.pos2 = reinterpret_cast<const v2d*>(d_pos);
@@ -272,36 +294,76 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     in.image = reinterpret_cast<const int*>(d_image);
     Partials part {ws->d_part, ws->d_ipart, ws->max_parts};
     const unsigned n = (unsigned)N;
-
-    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
     int st;
-    if ((st = evs.mark(0)) != CAVMD_OK)
-        return st;
-    hipLaunchKernelGGL((dipole_partials_kernel<AosInput, kReduceBlock, kReduceUnroll>), dim3(g1), dim3(kReduceBlock), 0,
-                       stream, in, n, Lx, Ly, Lz, L_typeid, part);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(1)) != CAVMD_OK)
+
+    // ---- launch 1: per-block partial sums + photon search
+    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
+    // by the force map: keeping it temporal lets the map hit it in the Infinity Cache while 8 N bytes are small
+    // (measured -4 % per evaluation at N = 1e6) but costs +16 % at N = 1e7, where it only evicts useful lines.
+    int nt = ws->reduce_nt_load;
+    if (nt < 0)
+        nt = (N <= kChargeTemporalMaxN) ? 1 : 2;
+#define CAVMD_LAUNCH_REDUCE(NTMODE, PIPE)                                                                             \
+    {                                                                                                                 \
+        AosInputT<NTMODE> inx {in.pos2, in.charge, in.image};                                                         \
+        st = ls.launch(0, dipole_partials_kernel<AosInputT<NTMODE>, kReduceBlock, kReduceUnroll, PIPE>, g1,           \
+                       kReduceBlock, inx, n, Lx, Ly, Lz, L_typeid, part);                                             \
+    }
+    if (ws->reduce_pipeline)
+    {
+        if (nt == 0)
+            CAVMD_LAUNCH_REDUCE(0, true)
+        else if (nt == 1)
+            CAVMD_LAUNCH_REDUCE(1, true)
+        else
+            CAVMD_LAUNCH_REDUCE(2, true)
+    }
+    else
+    {
+        if (nt == 0)
+            CAVMD_LAUNCH_REDUCE(0, false)
+        else if (nt == 1)
+            CAVMD_LAUNCH_REDUCE(1, false)
+        else
+            CAVMD_LAUNCH_REDUCE(2, false)
+    }
+#undef CAVMD_LAUNCH_REDUCE
+    if (st != CAVMD_OK)
         return st;
 
     ws->sequence += 1;
-    hipLaunchKernelGGL((finalize_kernel<AosInput, kFinalizeBlock>), dim3(1), dim3(kFinalizeBlock), 0, stream, in, n, g1,
-                       Lx, Ly, Lz, *params, part, ws->sequence, ws->d_result);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(2)) != CAVMD_OK)
-        return st;
-
     const unsigned g2 = grid_for(2 * N, kMapBlock * kMapUnroll, ws->num_cu, ws->map_blocks_per_cu);
     v2d* force2 = reinterpret_cast<v2d*>(d_force);
-    if (ws->map_nt_store)
-        hipLaunchKernelGGL((force_map_aos_kernel<kMapBlock, kMapUnroll, true>), dim3(g2), dim3(kMapBlock), 0, stream,
-                           d_charge, in.pos2, n, params->couplstr, L_typeid, ws->d_result, force2);
+    if (ws->fused_finalize)
+    {
+        // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
+        if (ws->map_nt_store)
+            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
+                           Lz, *params, L_typeid, part, ws->sequence, ws->d_result, force2);
+        else
+            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, in, n, g1, Lx, Ly,
+                           Lz, *params, L_typeid, part, ws->sequence, ws->d_result, force2);
+    }
     else
-        hipLaunchKernelGGL((force_map_aos_kernel<kMapBlock, kMapUnroll, false>), dim3(g2), dim3(kMapBlock), 0, stream,
-                           d_charge, in.pos2, n, params->couplstr, L_typeid, ws->d_result, force2);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(3)) != CAVMD_OK)
+    {
+        // ---- three-launch variant (kept for A/B): finalize, then a force map that reads the result block
+        st = ls.launch(1, finalize_kernel<AosInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, *params,
+                       part, ws->sequence, ws->d_result);
+        if (st != CAVMD_OK)
+            return st;
+        const cavmd_result* res = ws->d_result;
+        const double g = params->couplstr;
+        if (ws->map_nt_store)
+            st = ls.launch(2, force_map_aos_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, d_charge, in.pos2, n, g,
+                           L_typeid, res, force2);
+        else
+            st = ls.launch(2, force_map_aos_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, d_charge, in.pos2, n, g,
+                           L_typeid, res, force2);
+    }
+    if (st != CAVMD_OK)
         return st;
-    evs.commit();
+    ls.commit();
 
     ws->last_stream = stream;
     ws->computed = true;
@@ -333,9 +395,9 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    EventScope evs(ws, stream);
-    if (evs.status != CAVMD_OK)
-        return evs.status;
+    LaunchScope ls(ws, stream);
+    if (ls.status != CAVMD_OK)
+        return ls.status;
 
     StridedInput in;
     in.pos = reinterpret_cast<const char*>(d_position);
@@ -350,30 +412,23 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
     const unsigned n = (unsigned)N;
 
     const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
-    int st;
-    if ((st = evs.mark(0)) != CAVMD_OK)
+    int st = ls.launch(0, dipole_partials_kernel<StridedInput, kReduceBlock, kReduceUnroll, false>, g1, kReduceBlock, in,
+                       n, Lx, Ly, Lz, L_typeid, part);
+    if (st != CAVMD_OK)
         return st;
-    hipLaunchKernelGGL((dipole_partials_kernel<StridedInput, kReduceBlock, kReduceUnroll>), dim3(g1), dim3(kReduceBlock),
-                       0, stream, in, n, Lx, Ly, Lz, L_typeid, part);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(1)) != CAVMD_OK)
-        return st;
-
     ws->sequence += 1;
-    hipLaunchKernelGGL((finalize_kernel<StridedInput, kFinalizeBlock>), dim3(1), dim3(kFinalizeBlock), 0, stream, in, n,
-                       g1, Lx, Ly, Lz, *params, part, ws->sequence, ws->d_result);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(2)) != CAVMD_OK)
+    st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, *params,
+                   part, ws->sequence, ws->d_result);
+    if (st != CAVMD_OK)
         return st;
-
-    const unsigned g2 = grid_for(N, kMapBlock, ws->num_cu, ws->map_blocks_per_cu);
-    hipLaunchKernelGGL((force_map_strided_kernel<kMapBlock>), dim3(g2), dim3(kMapBlock), 0, stream, in, n,
-                       params->couplstr, L_typeid, ws->d_result, reinterpret_cast<char*>(d_force), force_stride,
-                       reinterpret_cast<char*>(d_potential_energy), potential_energy_stride);
-    CAVMD_HIP_TRY(hipGetLastError());
-    if ((st = evs.mark(3)) != CAVMD_OK)
+    const unsigned g2 = grid_for(N, kMapBlock, ws->num_cu, 8);
+    const cavmd_result* res = ws->d_result;
+    st = ls.launch(2, force_map_strided_kernel<kMapBlock>, g2, kMapBlock, in, n, params->couplstr, L_typeid, res,
+                   reinterpret_cast<char*>(d_force), force_stride, reinterpret_cast<char*>(d_potential_energy),
+                   potential_energy_stride);
+    if (st != CAVMD_OK)
         return st;
-    evs.commit();
+    ls.commit();
 
     ws->last_stream = stream;
     ws->computed = true;
@@ -428,7 +483,8 @@ int cavmd_profile_enable(cavmd_workspace* ws, int on)
     DeviceGuard guard(ws->device);
     if (on && ws->events.empty())
     {
-        ws->events.resize(4 * kProfileSlots);
+        ws->events.resize(kEventsPerSlot * kProfileSlots);
+        ws->slot_mask.assign(kProfileSlots, 0);
         for (size_t i = 0; i < ws->events.size(); ++i)
         {
             hipError_t e = hipEventCreate(&ws->events[i]);
@@ -494,6 +550,27 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->map_nt_store = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "reduce_nt_load"))
+    {
+        if (value < -1 || value > 2)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->reduce_nt_load = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "reduce_pipeline"))
+    {
+        if (value != 0 && value != 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->reduce_pipeline = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "fused_finalize"))
+    {
+        if (value != 0 && value != 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->fused_finalize = value;
+        return CAVMD_OK;
+    }
     return CAVMD_ERR_INVALID_VALUE;
 }
 
@@ -507,6 +584,12 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->map_blocks_per_cu;
     else if (!strcmp(name, "map_nt_store"))
         *value = ws->map_nt_store;
+    else if (!strcmp(name, "reduce_nt_load"))
+        *value = ws->reduce_nt_load;
+    else if (!strcmp(name, "fused_finalize"))
+        *value = ws->fused_finalize;
+    else if (!strcmp(name, "reduce_pipeline"))
+        *value = ws->reduce_pipeline;
     else
         return CAVMD_ERR_INVALID_VALUE;
     return CAVMD_OK;

@@ -31,6 +31,12 @@
 // roundings on the device too, and keep the TwoSum error terms from being "simplified".
 #pragma clang fp contract(off)
 
+// Diagnostic hook: a developer build (csrc/microbench.hip) defines CAVMD_STAMP(k) to record s_memtime at
+// numbered points of the finalize chain; in the product it expands to nothing.
+#ifndef CAVMD_STAMP
+#define CAVMD_STAMP(k)
+#endif
+
 namespace cavmd
 {
 
@@ -70,9 +76,21 @@ __device__ __forceinline__ void dd_norm(double& hi, double& lo)
     lo = e;
 }
 
-__device__ __forceinline__ double shfl_down_f64(double v, int delta)
+// ---- cross-lane movement: DPP (data-parallel primitives), no LDS crossbar round trip -----------------------------
+// dpp_ctrl encodings (GFX9 family, which gfx950 belongs to): quad_perm[a,b,c,d] = a|b<<2|c<<4|d<<6,
+// row_half_mirror 0x141, row_mirror 0x140, row_bcast:15 0x142, row_bcast:31 0x143.  A "row" is 16 lanes.
+// Lanes that the control/row mask does not write receive `ident`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v, double ident)
 {
-    return __shfl_down(v, delta, kWave);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v, int ident)
+{
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
 }
 
 // Per-lane running state of the reduction.
@@ -110,41 +128,46 @@ struct Accum
         lmin = min(lmin, o.lmin);
         lcnt += o.lcnt;
     }
-    __device__ __forceinline__ Accum shfl_down(int delta) const
+    // one step of the wave tree: combine with the lane the DPP control selects
+    template <int CTRL, int ROW_MASK>
+    __device__ __forceinline__ void dpp_step(bool withL)
     {
-        Accum o;
-        o.hx = shfl_down_f64(hx, delta);
-        o.lx = shfl_down_f64(lx, delta);
-        o.hy = shfl_down_f64(hy, delta);
-        o.ly = shfl_down_f64(ly, delta);
-        o.hz = shfl_down_f64(hz, delta);
-        o.lz = shfl_down_f64(lz, delta);
-        o.sx = shfl_down_f64(sx, delta);
-        o.sy = shfl_down_f64(sy, delta);
-        o.sz = shfl_down_f64(sz, delta);
-        o.lmin = __shfl_down(lmin, delta, kWave);
-        o.lcnt = __shfl_down(lcnt, delta, kWave);
-        return o;
+        dd_merge(hx, lx, dpp_f64<CTRL, ROW_MASK>(hx, 0.0), dpp_f64<CTRL, ROW_MASK>(lx, 0.0));
+        dd_merge(hy, ly, dpp_f64<CTRL, ROW_MASK>(hy, 0.0), dpp_f64<CTRL, ROW_MASK>(ly, 0.0));
+        dd_merge(hz, lz, dpp_f64<CTRL, ROW_MASK>(hz, 0.0), dpp_f64<CTRL, ROW_MASK>(lz, 0.0));
+        if (withL)
+        {
+            sx += dpp_f64<CTRL, ROW_MASK>(sx, 0.0);
+            sy += dpp_f64<CTRL, ROW_MASK>(sy, 0.0);
+            sz += dpp_f64<CTRL, ROW_MASK>(sz, 0.0);
+            lmin = min(lmin, dpp_i32<CTRL, ROW_MASK>(lmin, INT_MAX));
+            lcnt += dpp_i32<CTRL, ROW_MASK>(lcnt, 0);
+        }
     }
 };
 
-// Fixed-shape block reduction: lanes -> wave (5+1 shuffle steps) -> LDS -> thread 0 folds the waves in
-// wave order.  Returns the block total in thread 0 (other threads hold partial garbage).
+// Fixed-shape block reduction.  Wave tree in six DPP steps (xor 1, xor 2 inside quads; mirror inside 8 and inside
+// 16 lanes; row 0->1 and 2->3; rows 0-1 -> rows 2-3) that leave the wave total in lane 63, then one LDS hop and
+// thread 0 folds the waves in wave order.  Returns the block total in thread 0 (other threads hold partial sums).
+// L-typed particles are rare (normally one in the whole system): a wave that has seen none moves only the six
+// doubles of the molecular sum through the tree (wave-uniform branch).
 template <int BLOCK>
 __device__ __forceinline__ Accum block_reduce(Accum a)
 {
     constexpr int NW = BLOCK / kWave;
     __shared__ double s_d[NW][kNumPartDoubles];
     __shared__ int s_i[NW][kNumPartInts];
-#pragma unroll
-    for (int delta = kWave / 2; delta > 0; delta >>= 1)
-    {
-        const Accum o = a.shfl_down(delta);
-        a.merge(o);
-    }
+    const bool anyL = __any(a.lcnt != 0);
+    a.dpp_step<0xB1, 0xF>(anyL);  // quad_perm [1,0,3,2]
+    a.dpp_step<0x4E, 0xF>(anyL);  // quad_perm [2,3,0,1]
+    a.dpp_step<0x141, 0xF>(anyL); // row_half_mirror
+    a.dpp_step<0x140, 0xF>(anyL); // row_mirror: every lane of a row now holds the row total
+    a.dpp_step<0x142, 0xA>(anyL); // row_bcast:15 into rows 1 and 3
+    a.dpp_step<0x143, 0xC>(anyL); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave total
+    CAVMD_STAMP(2);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    if (lane == 0)
+    if (lane == kWave - 1)
     {
         s_d[wave][0] = a.hx; s_d[wave][1] = a.lx; s_d[wave][2] = a.hy; s_d[wave][3] = a.ly;
         s_d[wave][4] = a.hz; s_d[wave][5] = a.lz; s_d[wave][6] = a.sx; s_d[wave][7] = a.sy;
@@ -155,6 +178,11 @@ __device__ __forceinline__ Accum block_reduce(Accum a)
     __syncthreads();
     if (threadIdx.x == 0)
     {
+        a.hx = s_d[0][0]; a.lx = s_d[0][1]; a.hy = s_d[0][2]; a.ly = s_d[0][3];
+        a.hz = s_d[0][4]; a.lz = s_d[0][5]; a.sx = s_d[0][6]; a.sy = s_d[0][7];
+        a.sz = s_d[0][8];
+        a.lmin = s_i[0][0];
+        a.lcnt = s_i[0][1];
 #pragma unroll
         for (int w = 1; w < NW; ++w)
         {
@@ -167,12 +195,16 @@ __device__ __forceinline__ Accum block_reduce(Accum a)
             a.merge(o);
         }
     }
+    CAVMD_STAMP(3);
     return a;
 }
 
 // ---- input layouts -------------------------------------------------------------------------------
 // HOOMD-native AoS: Scalar4 pos (type tag in the low 32 bits of .w), Scalar charge, int3 image.
-struct AosInput
+// NT: 0 = plain loads, 1 = pos and image non-temporal (read once per evaluation) but charge temporal (the force
+// map reads it again), 2 = all three non-temporal.
+template <int NT>
+struct AosInputT
 {
     const v2d* __restrict__ pos2;      // 2 x 16 B per particle
     const double* __restrict__ charge;
@@ -187,13 +219,25 @@ struct AosInput
     __device__ __forceinline__ Raw load(size_t i) const
     {
         Raw r;
-        r.xy = pos2[2 * i];
-        r.zw = pos2[2 * i + 1];
-        r.c = charge[i];
         const int* im = image + 3 * i;
-        r.ix = im[0];
-        r.iy = im[1];
-        r.iz = im[2];
+        if (NT)
+        {
+            r.xy = __builtin_nontemporal_load(pos2 + 2 * i);
+            r.zw = __builtin_nontemporal_load(pos2 + 2 * i + 1);
+            r.c = (NT == 2) ? __builtin_nontemporal_load(charge + i) : charge[i];
+            r.ix = __builtin_nontemporal_load(im + 0);
+            r.iy = __builtin_nontemporal_load(im + 1);
+            r.iz = __builtin_nontemporal_load(im + 2);
+        }
+        else
+        {
+            r.xy = pos2[2 * i];
+            r.zw = pos2[2 * i + 1];
+            r.c = charge[i];
+            r.ix = im[0];
+            r.iy = im[1];
+            r.iz = im[2];
+        }
         return r;
     }
     static __device__ __forceinline__ double x(const Raw& r) { return r.xy.x; }
@@ -201,6 +245,7 @@ struct AosInput
     static __device__ __forceinline__ double z(const Raw& r) { return r.zw.x; }
     static __device__ __forceinline__ int tag(const Raw& r) { return __double2loint(r.zw.y); }
 };
+typedef AosInputT<0> AosInput;
 
 // Snapshot layout with byte strides: position (N,3) f64, typeid (N,) i32, image (N,3) i32, charge (N,) f64.
 struct StridedInput
@@ -246,31 +291,106 @@ struct Partials
 };
 
 // ---- kernel 1: per-block partial dipole sums + photon search --------------------------------------
+// One tile = BLOCK * UNROLL particles; block b takes tiles b, b + grid, ...  All UNROLL particles' loads of a lane are
+// issued together (16 loads in flight per lane at UNROLL = 4; a scheduling barrier keeps hipcc from sinking them
+// behind each other's waits).  PIPE = 1 additionally double-buffers tiles: the next tile's loads are issued before
+// the current tile's arithmetic, so that the ~57 VALU operations per particle overlap with memory even at one wave
+// per SIMD.
+template <class Input, int UNROLL>
+struct TileRegs
+{
+    typename Input::Raw raw[UNROLL];
+};
+
 template <class Input, int BLOCK, int UNROLL>
+__device__ __forceinline__ void tile_load(const Input& in, size_t base, TileRegs<Input, UNROLL>& r)
+{
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+        r.raw[u] = in.load(base + (size_t)u * BLOCK);
+}
+
+template <class Input, int BLOCK, int UNROLL>
+__device__ __forceinline__ void tile_accumulate(const TileRegs<Input, UNROLL>& r, size_t base, double Lx, double Ly,
+                                                double Lz, int L_typeid, Accum& acc)
+{
+    bool isL[UNROLL];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+    {
+        isL[u] = (Input::tag(r.raw[u]) == L_typeid);
+        any = any || isL[u];
+    }
+    if (!__any(any))
+    {
+        // fast path (wave-uniform): no lane of this wave holds an L-typed particle in this tile
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const double c = r.raw[u].c;
+            dd_acc(acc.hx, acc.lx, c * (Input::x(r.raw[u]) + (double)r.raw[u].ix * Lx));
+            dd_acc(acc.hy, acc.ly, c * (Input::y(r.raw[u]) + (double)r.raw[u].iy * Ly));
+            dd_acc(acc.hz, acc.lz, c * (Input::z(r.raw[u]) + (double)r.raw[u].iz * Lz));
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const double rx = Input::x(r.raw[u]) + (double)r.raw[u].ix * Lx;
+            const double ry = Input::y(r.raw[u]) + (double)r.raw[u].iy * Ly;
+            const double rz = Input::z(r.raw[u]) + (double)r.raw[u].iz * Lz;
+            acc.add((unsigned)(base + (size_t)u * BLOCK), rx, ry, rz, r.raw[u].c, Input::tag(r.raw[u]), L_typeid);
+        }
+    }
+}
+
+template <class Input, int BLOCK, int UNROLL, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void dipole_partials_kernel(Input in, unsigned N, double Lx, double Ly, double Lz,
                                                                 int L_typeid, Partials part)
 {
     constexpr unsigned TILE = BLOCK * UNROLL;
     Accum acc;
     const unsigned full_tiles = N / TILE;
-    for (unsigned t = blockIdx.x; t < full_tiles; t += gridDim.x)
+    const unsigned G = gridDim.x;
+    if (!PIPE)
     {
-        const size_t base = (size_t)t * TILE + threadIdx.x;
-        typename Input::Raw raw[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            raw[u] = in.load(base + (size_t)u * BLOCK);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (unsigned t = blockIdx.x; t < full_tiles; t += G)
         {
-            const double rx = Input::x(raw[u]) + (double)raw[u].ix * Lx;
-            const double ry = Input::y(raw[u]) + (double)raw[u].iy * Ly;
-            const double rz = Input::z(raw[u]) + (double)raw[u].iz * Lz;
-            acc.add((unsigned)(base + (size_t)u * BLOCK), rx, ry, rz, raw[u].c, Input::tag(raw[u]), L_typeid);
+            const size_t base = (size_t)t * TILE + threadIdx.x;
+            TileRegs<Input, UNROLL> A;
+            tile_load<Input, BLOCK, UNROLL>(in, base, A);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_accumulate<Input, BLOCK, UNROLL>(A, base, Lx, Ly, Lz, L_typeid, acc);
+        }
+    }
+    else
+    {
+        // ping-pong A/B so that no register copies are needed
+        TileRegs<Input, UNROLL> A, B;
+        unsigned t = blockIdx.x;
+        if (t < full_tiles)
+            tile_load<Input, BLOCK, UNROLL>(in, (size_t)t * TILE + threadIdx.x, A);
+        while (t < full_tiles)
+        {
+            if (t + G < full_tiles)
+                tile_load<Input, BLOCK, UNROLL>(in, (size_t)(t + G) * TILE + threadIdx.x, B);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_accumulate<Input, BLOCK, UNROLL>(A, (size_t)t * TILE + threadIdx.x, Lx, Ly, Lz, L_typeid, acc);
+            t += G;
+            if (t >= full_tiles)
+                break;
+            if (t + G < full_tiles)
+                tile_load<Input, BLOCK, UNROLL>(in, (size_t)(t + G) * TILE + threadIdx.x, A);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_accumulate<Input, BLOCK, UNROLL>(B, (size_t)t * TILE + threadIdx.x, Lx, Ly, Lz, L_typeid, acc);
+            t += G;
         }
     }
     // ragged tail: one block takes it, bounds-checked
-    if (blockIdx.x == full_tiles % gridDim.x)
+    if (blockIdx.x == full_tiles % G)
     {
         const size_t base = (size_t)full_tiles * TILE + threadIdx.x;
 #pragma unroll
@@ -300,90 +420,150 @@ __global__ __launch_bounds__(BLOCK) void dipole_partials_kernel(Input in, unsign
     }
 }
 
-// ---- kernel 2: final reduction + scalars ------------------------------------------------------------
-template <class Input, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void finalize_kernel(Input in, unsigned N, unsigned nparts, double Lx, double Ly,
-                                                         double Lz, cavmd_params prm, Partials part, uint64_t sequence,
-                                                         cavmd_result* __restrict__ res)
+// ---- final reduction + scalars (shared by the stand-alone finalize kernel and the fused force map) ------------
+// Everything an evaluation produces besides the per-particle forces, as held by thread 0 of a block.
+struct Scalars
 {
+    double d[3], dlo[3], q[3], Dq[2], e[3], f[3];
+    int photon, nL;
+};
+
+// Folds the `nparts` per-block partials in a FIXED order (thread t takes partials t, t+BLOCK, ... in index order,
+// then the fixed-shape block tree), unwraps the photon and evaluates energies, Dq and the photon force with the
+// reference's operator association (src/CavityForceCompute.cc:169-183, 203-207).  All threads of the block must
+// call it; the result is valid in thread 0 only.  Any block that calls it with the same arguments gets the same
+// bits, which is what lets every block of the fused force map redo it instead of waiting on a separate launch.
+template <class Input, int BLOCK>
+__device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in, unsigned N, unsigned nparts, double Lx,
+                                                                double Ly, double Lz, const cavmd_params& prm,
+                                                                const Partials& part)
+{
+    // Speculative fetch of the last particle: the driver appends the photon last (examples/05_advanced_run.py:
+    // 497-505), so this usually removes a dependent memory round trip after the reduction.
+    CAVMD_STAMP(0);
+    const typename Input::Raw guess = in.load((size_t)(N - 1));
+
     Accum acc;
     const unsigned s = part.stride;
-    // thread t folds partials t, t+BLOCK, ... in index order: a fixed tree for a fixed nparts
-    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
+    constexpr int BATCH = 4; // partial sets in flight per thread
+    for (unsigned base = 0; base < nparts; base += BATCH * BLOCK)
     {
-        Accum o;
-        o.hx = part.d[0 * s + p]; o.lx = part.d[1 * s + p];
-        o.hy = part.d[2 * s + p]; o.ly = part.d[3 * s + p];
-        o.hz = part.d[4 * s + p]; o.lz = part.d[5 * s + p];
-        o.sx = part.d[6 * s + p]; o.sy = part.d[7 * s + p]; o.sz = part.d[8 * s + p];
-        o.lmin = part.i[0 * s + p];
-        o.lcnt = part.i[1 * s + p];
-        acc.merge(o);
+        Accum o[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned p = base + j * BLOCK + threadIdx.x;
+            if (p < nparts)
+            {
+                o[j].hx = part.d[0 * s + p]; o[j].lx = part.d[1 * s + p];
+                o[j].hy = part.d[2 * s + p]; o[j].ly = part.d[3 * s + p];
+                o[j].hz = part.d[4 * s + p]; o[j].lz = part.d[5 * s + p];
+                o[j].sx = part.d[6 * s + p]; o[j].sy = part.d[7 * s + p]; o[j].sz = part.d[8 * s + p];
+                o[j].lmin = part.i[0 * s + p];
+                o[j].lcnt = part.i[1 * s + p];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (base + j * BLOCK < nparts) // block-uniform: skip batches nobody loaded
+                acc.merge(o[j]);           // (a default-constructed Accum is the identity for the ragged last one)
     }
+    CAVMD_STAMP(1);
     acc = block_reduce<BLOCK>(acc);
-    if (threadIdx.x != 0)
-        return;
 
+    Scalars sc;
     dd_norm(acc.hx, acc.lx);
     dd_norm(acc.hy, acc.ly);
     dd_norm(acc.hz, acc.lz);
     double dx = acc.hx, dy = acc.hy, dz = acc.hz;
     const int photon = (acc.lmin == INT_MAX) ? -1 : acc.lmin;
-
     const double g = prm.couplstr, K = prm.K;
-    double qx = 0.0, qy = 0.0, qz = 0.0;
-    double eh = 0.0, ec = 0.0, ed = 0.0;
-    double Dqx = 0.0, Dqy = 0.0;
-    double fx = 0.0, fy = 0.0, fz = 0.0;
-    if (photon >= 0)
+    double qx = 0.0, qy = 0.0, qz = 0.0, eh = 0.0, ec = 0.0, ed = 0.0, Dqx = 0.0, Dqy = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+    if (threadIdx.x == 0)
     {
-        const typename Input::Raw r = in.load((size_t)photon);
-        qx = Input::x(r) + (double)r.ix * Lx;
-        qy = Input::y(r) + (double)r.iy * Ly;
-        qz = Input::z(r) + (double)r.iz * Lz;
-        if (acc.lcnt > 1)
+        if (photon >= 0)
         {
-            // Degenerate input (the driver enforces exactly one 'L', examples/05_advanced_run.py:548-550):
-            // the reference skips only the FIRST L-typed particle in the dipole (src/CavityForceCompute.cc:122),
-            // so the later ones are added back here.
-            dx += acc.sx - r.c * qx;
-            dy += acc.sy - r.c * qy;
-            dz += acc.sz - r.c * qz;
+            typename Input::Raw r = guess;
+            if ((unsigned)photon != N - 1)
+                r = in.load((size_t)photon);
+            qx = Input::x(r) + (double)r.ix * Lx;
+            qy = Input::y(r) + (double)r.iy * Ly;
+            qz = Input::z(r) + (double)r.iz * Lz;
+            if (acc.lcnt > 1)
+            {
+                // Degenerate input (the driver enforces exactly one 'L', examples/05_advanced_run.py:548-550): the
+                // reference skips only the FIRST L-typed particle in the dipole (src/CavityForceCompute.cc:122), so
+                // the later ones are added back here.
+                dx += acc.sx - r.c * qx;
+                dy += acc.sy - r.c * qy;
+                dz += acc.sz - r.c * qz;
+            }
+            // src/CavityForceCompute.cc:174-176, dot() = a.x*b.x + a.y*b.y + a.z*b.z
+            eh = 0.5 * K * (qx * qx + qy * qy + qz * qz);
+            ec = g * (dx * qx + dy * qy + 0.0 * 0.0);
+            ed = 0.5 * (g * g / K) * (dx * dx + dy * dy + 0.0 * 0.0);
+            // :183
+            const double gK = g / K;
+            Dqx = qx + gK * dx;
+            Dqy = qy + gK * dy;
+            // :203-207
+            fx = -K * qx - g * dx;
+            fy = -K * qy - g * dy;
+            fz = -K * qz - g * 0.0;
         }
-        // src/CavityForceCompute.cc:174-176, dot() = a.x*b.x + a.y*b.y + a.z*b.z
-        eh = 0.5 * K * (qx * qx + qy * qy + qz * qz);
-        ec = g * (dx * qx + dy * qy + 0.0 * 0.0);
-        ed = 0.5 * (g * g / K) * (dx * dx + dy * dy + 0.0 * 0.0);
-        // :183
-        const double gK = g / K;
-        Dqx = qx + gK * dx;
-        Dqy = qy + gK * dy;
-        // :203-207
-        fx = -K * qx - g * dx;
-        fy = -K * qy - g * dy;
-        fz = -K * qz - g * 0.0;
+        else
+        {
+            // no photon: the reference zeroes energies and returns before it computes a dipole (:148-156)
+            dx = dy = dz = 0.0;
+            acc.lx = acc.ly = acc.lz = 0.0;
+        }
     }
-    else
+    CAVMD_STAMP(4);
+    sc.d[0] = dx; sc.d[1] = dy; sc.d[2] = dz;
+    sc.dlo[0] = acc.lx; sc.dlo[1] = acc.ly; sc.dlo[2] = acc.lz;
+    sc.q[0] = qx; sc.q[1] = qy; sc.q[2] = qz;
+    sc.Dq[0] = Dqx; sc.Dq[1] = Dqy;
+    sc.e[0] = eh; sc.e[1] = ec; sc.e[2] = ed;
+    sc.f[0] = fx; sc.f[1] = fy; sc.f[2] = fz;
+    sc.photon = photon;
+    sc.nL = acc.lcnt;
+    return sc;
+}
+
+__device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, const Scalars& sc, unsigned N,
+                                             unsigned nparts, uint64_t sequence)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
     {
-        // no photon: the reference zeroes energies and returns before it computes a dipole (:148-156)
-        dx = dy = dz = 0.0;
-        acc.lx = acc.ly = acc.lz = 0.0;
+        res->dipole[k] = sc.d[k];
+        res->q[k] = sc.q[k];
+        res->energy[k] = sc.e[k];
+        res->photon_force[k] = sc.f[k];
+        res->dipole_lo[k] = sc.dlo[k];
     }
-    res->dipole[0] = dx; res->dipole[1] = dy; res->dipole[2] = dz;
-    res->q[0] = qx; res->q[1] = qy; res->q[2] = qz;
-    res->Dq[0] = Dqx; res->Dq[1] = Dqy;
-    res->energy[0] = eh; res->energy[1] = ec; res->energy[2] = ed;
-    res->photon_force[0] = fx; res->photon_force[1] = fy; res->photon_force[2] = fz;
-    res->dipole_lo[0] = acc.lx; res->dipole_lo[1] = acc.ly; res->dipole_lo[2] = acc.lz;
-    res->photon_idx = photon;
-    res->n_photon_typed = acc.lcnt;
+    res->Dq[0] = sc.Dq[0];
+    res->Dq[1] = sc.Dq[1];
+    res->photon_idx = sc.photon;
+    res->n_photon_typed = sc.nL;
     res->n_particles = N;
     res->n_partials = nparts;
     res->sequence = sequence;
     res->reserved[0] = res->reserved[1] = res->reserved[2] = res->reserved[3] = 0.0;
 }
 
-// ---- kernel 3: force map, HOOMD AoS force array written as dense 16-byte chunks ---------------------
+// ---- kernel 2 (three-launch path): one block publishes the result block ---------------------------------------
+template <class Input, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(Input in, unsigned N, unsigned nparts, double Lx, double Ly,
+                                                         double Lz, cavmd_params prm, Partials part, uint64_t sequence,
+                                                         cavmd_result* __restrict__ res)
+{
+    const Scalars sc = reduce_partials_and_finalize<Input, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part);
+    if (threadIdx.x == 0)
+        write_result(res, sc, N, nparts, sequence);
+}
+
+// ---- force map, HOOMD AoS force array written as dense 16-byte chunks ------------------------------------------
 template <bool NT>
 __device__ __forceinline__ void store_chunk(v2d* p, v2d v)
 {
@@ -393,25 +573,31 @@ __device__ __forceinline__ void store_chunk(v2d* p, v2d v)
         *p = v;
 }
 
-template <int BLOCK, int UNROLL, bool NT>
-__global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __restrict__ charge,
-                                                              const v2d* __restrict__ pos2, // only read if several L-typed
-                                                              unsigned N, double g, int L_typeid,
-                                                              const cavmd_result* __restrict__ res, v2d* __restrict__ force2)
+// What every thread of the force map needs to know about the evaluation.
+struct MapScalars
 {
-    constexpr unsigned TILE = BLOCK * UNROLL; // in 16-byte chunks; chunk k: particle k>>1, half k&1
-    const double Dqx = res->Dq[0], Dqy = res->Dq[1];
-    const int photon = res->photon_idx;
-    const int nL = res->n_photon_typed;
-    const double Fx = res->photon_force[0], Fy = res->photon_force[1], Fz = res->photon_force[2];
+    double Dqx, Dqy, Fx, Fy, Fz;
+    int photon, nL;
+};
+
+// Body shared by the three-launch and the fused force map.  Chunk k is 16 bytes: particle k>>1, half k&1.
+// Even chunk = (Fx, Fy) = ((-g c) Dq_x, (-g c) Dq_y), odd chunk = (Fz, w) = (0, 0); the photon's chunks carry F_L.
+// PRE: the caller has already loaded the charges of this block's first full tile into c_first (issued before its
+// prologue so that their latency is hidden behind it).
+template <int BLOCK, int UNROLL, bool NT, bool PRE>
+__device__ __forceinline__ void force_map_body(const MapScalars m, const double* __restrict__ charge,
+                                               const v2d* __restrict__ pos2, unsigned N, double g, int L_typeid,
+                                               v2d* __restrict__ force2, const double (&c_first)[UNROLL])
+{
+    constexpr unsigned TILE = BLOCK * UNROLL;
     const double ng = -g;
     const size_t nchunks = 2 * (size_t)N;
-    const size_t pchunk = photon >= 0 ? 2 * (size_t)photon : ~(size_t)0; // photon's first chunk
+    const size_t pchunk = m.photon >= 0 ? 2 * (size_t)m.photon : ~(size_t)0; // photon's first chunk
     const unsigned full_tiles = (unsigned)(nchunks / TILE);
     const bool odd = threadIdx.x & 1; // BLOCK and TILE are even, so the half is fixed per thread
     const v2d zero = {0.0, 0.0};
 
-    if (photon < 0)
+    if (m.photon < 0)
     {
         // no photon: all forces are zero (src/CavityForceCompute.cc:145-156)
         for (size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x; k < nchunks; k += (size_t)gridDim.x * BLOCK)
@@ -419,24 +605,33 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __re
         return;
     }
 
-    if (nL <= 1)
+    if (m.nL <= 1)
     {
         for (unsigned t = blockIdx.x; t < full_tiles; t += gridDim.x)
         {
             const size_t base = (size_t)t * TILE + threadIdx.x;
             double c[UNROLL];
+            if (PRE && t == blockIdx.x)
+            {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                c[u] = charge[(base + (size_t)u * BLOCK) >> 1];
+                for (int u = 0; u < UNROLL; ++u)
+                    c[u] = c_first[u];
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    c[u] = charge[(base + (size_t)u * BLOCK) >> 1];
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
             {
                 const size_t k = base + (size_t)u * BLOCK;
                 const double s = ng * c[u]; // ((-g) * charge) * Dq, src/CavityForceCompute.cc:194
-                v2d v = {s * Dqx, s * Dqy};
+                v2d v = {s * m.Dqx, s * m.Dqy};
                 v = odd ? zero : v;
                 if ((k | 1) == (pchunk | 1))
-                    v = odd ? (v2d) {Fz, 0.0} : (v2d) {Fx, Fy};
+                    v = odd ? (v2d) {m.Fz, 0.0} : (v2d) {m.Fx, m.Fy};
                 store_chunk<NT>(force2 + k, v);
             }
         }
@@ -450,10 +645,10 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __re
                 if (k < nchunks)
                 {
                     const double s = ng * charge[k >> 1];
-                    v2d v = {s * Dqx, s * Dqy};
+                    v2d v = {s * m.Dqx, s * m.Dqy};
                     v = odd ? zero : v;
                     if ((k | 1) == (pchunk | 1))
-                        v = odd ? (v2d) {Fz, 0.0} : (v2d) {Fx, Fy};
+                        v = odd ? (v2d) {m.Fz, 0.0} : (v2d) {m.Fx, m.Fy};
                     store_chunk<NT>(force2 + k, v);
                 }
             }
@@ -468,12 +663,69 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __re
         const size_t p = k >> 1;
         const int tag = __double2loint(pos2[2 * p + 1].y);
         const double s = ng * charge[p];
-        v2d v = {s * Dqx, s * Dqy};
+        v2d v = {s * m.Dqx, s * m.Dqy};
         v = (odd || tag == L_typeid) ? zero : v;
         if ((k | 1) == (pchunk | 1))
-            v = odd ? (v2d) {Fz, 0.0} : (v2d) {Fx, Fy};
+            v = odd ? (v2d) {m.Fz, 0.0} : (v2d) {m.Fx, m.Fy};
         store_chunk<NT>(force2 + k, v);
     }
+}
+
+// three-launch path: scalars come from the result block the finalize kernel wrote
+template <int BLOCK, int UNROLL, bool NT>
+__global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __restrict__ charge,
+                                                              const v2d* __restrict__ pos2, // only read if several L-typed
+                                                              unsigned N, double g, int L_typeid,
+                                                              const cavmd_result* __restrict__ res, v2d* __restrict__ force2)
+{
+    MapScalars m;
+    m.Dqx = res->Dq[0]; m.Dqy = res->Dq[1];
+    m.Fx = res->photon_force[0]; m.Fy = res->photon_force[1]; m.Fz = res->photon_force[2];
+    m.photon = res->photon_idx;
+    m.nL = res->n_photon_typed;
+    const double none[UNROLL] = {};
+    force_map_body<BLOCK, UNROLL, NT, false>(m, charge, pos2, N, g, L_typeid, force2, none);
+}
+
+// two-launch path: every block folds the partials itself (same fixed order -> same bits in every block), block 0
+// publishes the result block; no separate finalize launch and no inter-workgroup hand-off inside the launch.
+template <int BLOCK, int UNROLL, bool NT>
+__global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in, unsigned N, unsigned nparts, double Lx,
+                                                                    double Ly, double Lz, cavmd_params prm, int L_typeid,
+                                                                    Partials part, uint64_t sequence,
+                                                                    cavmd_result* __restrict__ res,
+                                                                    v2d* __restrict__ force2)
+{
+    __shared__ double s_m[5];
+    __shared__ int s_mi[2];
+    // charges of the first tile: independent of the prologue, so issue them first
+    double c_first[UNROLL] = {};
+    {
+        constexpr unsigned TILE = BLOCK * UNROLL;
+        const unsigned full_tiles = (unsigned)((2 * (size_t)N) / TILE);
+        if (blockIdx.x < full_tiles)
+        {
+            const size_t base = (size_t)blockIdx.x * TILE + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                c_first[u] = in.charge[(base + (size_t)u * BLOCK) >> 1];
+        }
+    }
+    const Scalars sc = reduce_partials_and_finalize<AosInput, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part);
+    if (threadIdx.x == 0)
+    {
+        s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
+        s_mi[0] = sc.photon;
+        s_mi[1] = sc.nL;
+        if (blockIdx.x == 0)
+            write_result(res, sc, N, nparts, sequence);
+    }
+    __syncthreads();
+    MapScalars m;
+    m.Dqx = s_m[0]; m.Dqy = s_m[1]; m.Fx = s_m[2]; m.Fy = s_m[3]; m.Fz = s_m[4];
+    m.photon = s_mi[0];
+    m.nL = s_mi[1];
+    force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.couplstr, L_typeid, force2, c_first);
 }
 
 // ---- kernel 3': force map for the snapshot layout (strided (N,3) force + optional potential energy) ---

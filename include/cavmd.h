@@ -185,13 +185,21 @@ CAVMD_API int cavmd_result_device_ptr(cavmd_workspace* ws, const cavmd_result** 
 /* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */
 CAVMD_API int cavmd_profile_enable(cavmd_workspace* ws, int on);
 /* Synchronises and returns the accumulated device time per kernel since the last reset:
- * ms[0] = dipole partial-sum kernel, ms[1] = finalize kernel, ms[2] = force-map kernel;
+ * ms[0] = dipole partial-sum kernel, ms[1] = finalize kernel (0 in the default two-launch mode, where the
+ * finalize is the prologue of the force map), ms[2] = force-map kernel;
  * *launches = evaluations accumulated.  Resets the accumulators. */
 CAVMD_API int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* launches);
 
 /* ---- tuning / introspection ------------------------------------------------------------------- */
-/* Launch geometry knobs; name is one of "reduce_blocks_per_cu", "map_blocks_per_cu", "map_nt_store".
- * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value. */
+/* Launch knobs (for A/B measurements; the defaults are the measured best on MI355X).  name is one of
+ *   "reduce_blocks_per_cu" 1..16   grid of the reduction = min(tiles, CUs * value); also the number of partials
+ *   "map_blocks_per_cu"    1..16   grid of the force map
+ *   "map_nt_store"         0/1     non-temporal force stores
+ *   "reduce_nt_load"       -1..2   -1 auto by N, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
+ *   "reduce_pipeline"      0/1     double-buffered tiles in the reduction
+ *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
+ * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value.  None of them changes results
+ * beyond the last bit of the dipole (different but fixed summation trees). */
 CAVMD_API int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value);
 CAVMD_API int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value);
 CAVMD_API int cavmd_device_info(cavmd_workspace* ws, int* device, int* compute_units, char* arch_name, size_t arch_name_len);

@@ -270,7 +270,7 @@ def test_several_L_typed_particles(ref, oracle_mod):
     for extra in (0, 99, 101, 2500, 4999):
         if extra != 100:
             cfg["typeid"][extra] = 2
-    cfg["typeid"][0] = 0  # photon is index 99? no: first L is 99
+    cfg["typeid"][0] = 0  # so the first L-typed particle (= the photon) is index 99, not 0
     gpu = gpu_eval(cfg)
     refout = ref_eval(ref, oracle_mod, cfg)
     assert gpu["photon_idx"] == refout["photon_idx"] == 99
@@ -302,7 +302,8 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     refout = ref_eval(ref, oracle_mod, cfg)
     check_parity(cfg, base, refout)
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
-                {"map_blocks_per_cu": 16, "map_nt_store": 1}):
+                {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
+                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_pipeline": 1}, {"reduce_pipeline": 1, "reduce_blocks_per_cu": 3}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
         assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))
