@@ -13,7 +13,10 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libcavmd.so")
+# in-tree build (this repository) first; next to this file when installed into HOOMD's python tree by
+# csrc/hoomd_shim/CMakeLists.txt
+_INSTALLED = os.path.join(_HERE, "libcavmd.so")
+LIB_PATH = _INSTALLED if (os.path.exists(_INSTALLED) and not os.path.isdir(CSRC_DIR)) else os.path.join(CSRC_DIR, "libcavmd.so")
 
 CAVMD_OK = 0
 CAVMD_ERR_INVALID_VALUE = -1

@@ -1,0 +1,156 @@
+// CavityForceComputeHIP.cc -- see the header.  UNBUILT in this repository's image (no HOOMD-blue headers).
+//
+// What the reference's GPU class does per step and this one does not (src/CavityForceComputeGPU.cc:129-226):
+// four hipMemsets, one H2D and two blocking D2H copies, hipDeviceSynchronize, a host ArrayHandle on the force AND
+// position arrays (a full device->host migration under GlobalArray) and an O(N) host scan.  Here: acquire four
+// device handles, enqueue two kernels on the null stream (HOOMD-blue's stream), release.  Energies are fetched
+// lazily, once per timestep, when a getter is called (EnergyTracker polls them every step at period 1).
+#include "CavityForceComputeHIP.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace hoomd
+    {
+namespace cavitymd
+    {
+static_assert(sizeof(Scalar) == 8, "libcavmd implements the double-precision (HOOMD_LONGREAL_SIZE=64) layouts");
+static_assert(sizeof(Scalar4) == sizeof(cavmd_double4), "Scalar4 layout");
+static_assert(sizeof(int3) == sizeof(cavmd_int3), "int3 layout");
+
+static void check(int status, const char* where)
+    {
+    if (status != CAVMD_OK)
+        throw std::runtime_error(std::string("cavitymd (HIP): ") + where + ": " + cavmd_error_string(status));
+    }
+
+CavityForceComputeHIP::CavityForceComputeHIP(std::shared_ptr<SystemDefinition> sysdef,
+                                             Scalar omegac,
+                                             Scalar couplstr,
+                                             Scalar phmass)
+    : ForceCompute(sysdef), m_params(cavmd_make_params(omegac, couplstr, phmass))
+    {
+    if (!m_exec_conf->isCUDAEnabled())
+        throw std::runtime_error("cavitymd (HIP): a GPU execution configuration is required; there is no CPU path");
+    ensureWorkspace(m_pdata->getMaxN());
+    }
+
+CavityForceComputeHIP::~CavityForceComputeHIP()
+    {
+    cavmd_destroy(m_ws);
+    }
+
+void CavityForceComputeHIP::ensureWorkspace(size_t n)
+    {
+    if (m_ws && n <= m_capacity)
+        return;
+    cavmd_destroy(m_ws);
+    m_ws = nullptr;
+    m_capacity = n > 0 ? n : 1;
+    check(cavmd_create(-1, m_capacity, &m_ws), "cavmd_create");
+    }
+
+void CavityForceComputeHIP::setParams(Scalar omegac, Scalar couplstr, Scalar phmass)
+    {
+    m_params = cavmd_make_params(omegac, couplstr, phmass);
+    }
+
+pybind11::dict CavityForceComputeHIP::getParams()
+    {
+    pybind11::dict v;
+    v["omegac"] = m_params.omegac;
+    v["couplstr"] = m_params.couplstr;
+    v["K"] = m_params.K;
+    v["phmass"] = m_params.phmass;
+    return v;
+    }
+
+void CavityForceComputeHIP::computeForces(uint64_t timestep)
+    {
+    const unsigned int N = m_pdata->getN();
+    ensureWorkspace(N);
+
+    // the CPU reference lets getTypeByName throw when no type is named 'L'; its GPU class zeroes the energies
+    // instead (src/CavityForceComputeGPU.cc:114-123).  -1 matches no particle: forces and energies become zero.
+    int L_typeid = -1;
+    try
+        {
+        L_typeid = (int)m_pdata->getTypeByName("L");
+        }
+    catch (...)
+        {
+        }
+
+    const BoxDim box = m_pdata->getGlobalBox();
+    const Scalar3 L = box.getL();
+
+        {
+        ArrayHandle<Scalar4> d_pos(m_pdata->getPositions(), access_location::device, access_mode::read);
+        ArrayHandle<Scalar> d_charge(m_pdata->getCharges(), access_location::device, access_mode::read);
+        ArrayHandle<int3> d_image(m_pdata->getImages(), access_location::device, access_mode::read);
+        ArrayHandle<Scalar4> d_force(m_force, access_location::device, access_mode::overwrite);
+        // m_virial and m_torque are not touched: the reference leaves them zero as well.
+        check(cavmd_compute_hoomd(m_ws,
+                                  nullptr, // HOOMD-blue works on the null stream
+                                  N,
+                                  reinterpret_cast<const cavmd_double4*>(d_pos.data),
+                                  d_charge.data,
+                                  reinterpret_cast<const cavmd_int3*>(d_image.data),
+                                  L.x,
+                                  L.y,
+                                  L.z,
+                                  L_typeid,
+                                  &m_params,
+                                  reinterpret_cast<cavmd_double4*>(d_force.data)),
+              "cavmd_compute_hoomd");
+        }
+    m_last_timestep = timestep;
+    }
+
+void CavityForceComputeHIP::fetchEnergies()
+    {
+    if (m_energy_timestep == m_last_timestep && m_last_timestep != ~uint64_t(0))
+        return;
+    check(cavmd_energies(m_ws, m_energy), "cavmd_energies");
+    m_energy_timestep = m_last_timestep;
+    }
+
+Scalar CavityForceComputeHIP::getHarmonicEnergy()
+    {
+    fetchEnergies();
+    return m_energy[0];
+    }
+
+Scalar CavityForceComputeHIP::getCouplingEnergy()
+    {
+    fetchEnergies();
+    return m_energy[1];
+    }
+
+Scalar CavityForceComputeHIP::getDipoleSelfEnergy()
+    {
+    fetchEnergies();
+    return m_energy[2];
+    }
+
+namespace detail
+    {
+void export_CavityForceComputeHIP(pybind11::module& m)
+    {
+    pybind11::class_<CavityForceComputeHIP, ForceCompute, std::shared_ptr<CavityForceComputeHIP>>(
+        m,
+        "CavityForceComputeHIP")
+        .def(pybind11::init<std::shared_ptr<SystemDefinition>, Scalar, Scalar, Scalar>(),
+             pybind11::arg("sysdef"),
+             pybind11::arg("omegac"),
+             pybind11::arg("couplstr"),
+             pybind11::arg("phmass") = 1.0)
+        .def("setParams", &CavityForceComputeHIP::setParams)
+        .def("getParams", &CavityForceComputeHIP::getParams)
+        .def("getHarmonicEnergy", &CavityForceComputeHIP::getHarmonicEnergy)
+        .def("getCouplingEnergy", &CavityForceComputeHIP::getCouplingEnergy)
+        .def("getDipoleSelfEnergy", &CavityForceComputeHIP::getDipoleSelfEnergy);
+    }
+    } // namespace detail
+    } // namespace cavitymd
+    } // namespace hoomd
