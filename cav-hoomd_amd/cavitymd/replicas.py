@@ -60,7 +60,8 @@ class ReplicaContext:
     world_size: int
     local_rank: int
     backend: str | None
-    device: torch.device
+    device: torch.device            # where the replica computes
+    coll_device: torch.device = torch.device("cpu")  # where the (tiny) collective buffers live
 
     @property
     def is_distributed(self) -> bool:
@@ -77,14 +78,20 @@ def init_from_env(prefer_gpu: bool = True) -> ReplicaContext:
     if use_gpu:
         torch.cuda.set_device(device)
     backend = None
+    coll_device = torch.device("cpu")
     if world > 1:
-        backend = "nccl" if use_gpu else "gloo"
+        # nccl == RCCL over xGMI on the GPU box.  CAVMD_DIST_BACKEND=gloo keeps the compute on the GPU but runs the
+        # handful of control collectives over gloo: used to rehearse an N-rank job on a box with fewer GPUs than ranks
+        # (RCCL refuses two ranks on one device).
+        backend = os.environ.get("CAVMD_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        if backend == "nccl":
+            coll_device = device
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            kwargs = {"device_id": device} if use_gpu else {}
+            kwargs = {"device_id": device} if backend == "nccl" else {}
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
-    return ReplicaContext(rank, world, local, backend, device)
+    return ReplicaContext(rank, world, local, backend, device, coll_device)
 
 
 def pack_block(spec: dict) -> torch.Tensor:
@@ -112,7 +119,7 @@ def broadcast_spec(ctx: ReplicaContext, spec: dict | None) -> dict:
             raise ValueError("rank 0 must supply the spec")
         return unpack_block(pack_block(spec))
     block = pack_block(spec if (ctx.rank == 0 and spec is not None) else {})
-    block = block.to(ctx.device)
+    block = block.to(ctx.coll_device)
     dist.broadcast(block, src=0)
     return unpack_block(block)
 
@@ -125,7 +132,7 @@ def barrier(ctx: ReplicaContext) -> None:
 def max_over_ranks(ctx: ReplicaContext, value: float) -> float:
     if not ctx.is_distributed:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.coll_device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -133,7 +140,7 @@ def max_over_ranks(ctx: ReplicaContext, value: float) -> float:
 def sum_over_ranks(ctx: ReplicaContext, value: float) -> float:
     if not ctx.is_distributed:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.coll_device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 

@@ -102,6 +102,16 @@ inline int hip_status(hipError_t e)
             return (int)_e;              \
     } while (0)
 
+DeviceParams derive(const cavmd_params* p)
+{
+    DeviceParams d;
+    d.g = p->couplstr;
+    d.K = p->K;
+    d.gK = p->couplstr / p->K;                   // as `m_params.couplstr / m_params.K`, src/CavityForceCompute.cc:183
+    d.g2K = p->couplstr * p->couplstr / p->K;    // as `couplstr * couplstr / K`, :176 (host code is built -ffp-contract=off)
+    return d;
+}
+
 bool params_ok(const cavmd_params* p)
 {
     return p && isfinite(p->omegac) && isfinite(p->couplstr) && isfinite(p->K) && isfinite(p->phmass) && p->K != 0.0;
@@ -294,6 +304,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     in.image = reinterpret_cast<const int*>(d_image);
     Partials part {ws->d_part, ws->d_ipart, ws->max_parts};
     const unsigned n = (unsigned)N;
+    const DeviceParams dp = derive(params);
     int st;
 
     // ---- launch 1: per-block partial sums + photon search
@@ -340,15 +351,15 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
         if (ws->map_nt_store)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, *params, L_typeid, part, ws->sequence, ws->d_result, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, force2);
         else
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, *params, L_typeid, part, ws->sequence, ws->d_result, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, force2);
     }
     else
     {
         // ---- three-launch variant (kept for A/B): finalize, then a force map that reads the result block
-        st = ls.launch(1, finalize_kernel<AosInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, *params,
+        st = ls.launch(1, finalize_kernel<AosInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
                        part, ws->sequence, ws->d_result);
         if (st != CAVMD_OK)
             return st;
@@ -410,6 +421,7 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
     in.chg_stride = charge_stride;
     Partials part {ws->d_part, ws->d_ipart, ws->max_parts};
     const unsigned n = (unsigned)N;
+    const DeviceParams dp = derive(params);
 
     const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
     int st = ls.launch(0, dipole_partials_kernel<StridedInput, kReduceBlock, kReduceUnroll, false>, g1, kReduceBlock, in,
@@ -417,7 +429,7 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
     if (st != CAVMD_OK)
         return st;
     ws->sequence += 1;
-    st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, *params,
+    st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
                    part, ws->sequence, ws->d_result);
     if (st != CAVMD_OK)
         return st;

@@ -146,13 +146,44 @@ struct Accum
     }
 };
 
-// Fixed-shape block reduction.  Wave tree in six DPP steps (xor 1, xor 2 inside quads; mirror inside 8 and inside
-// 16 lanes; row 0->1 and 2->3; rows 0-1 -> rows 2-3) that leave the wave total in lane 63, then one LDS hop and
-// thread 0 folds the waves in wave order.  Returns the block total in thread 0 (other threads hold partial sums).
-// L-typed particles are rare (normally one in the whole system): a wave that has seen none moves only the six
-// doubles of the molecular sum through the tree (wave-uniform branch).
+// ---- block reduction ---------------------------------------------------------------------------------------------
+struct DD
+{
+    double hi, lo;
+};
+__device__ __forceinline__ DD dd_sel(bool c, DD a, DD b)
+{
+    DD r;
+    r.hi = c ? a.hi : b.hi;
+    r.lo = c ? a.lo : b.lo;
+    return r;
+}
+__device__ __forceinline__ DD dd_sum(DD a, DD b)
+{
+    dd_merge(a.hi, a.lo, b.hi, b.lo);
+    return a;
+}
+template <int CTRL>
+__device__ __forceinline__ DD dd_dpp(DD v)
+{
+    DD r;
+    r.hi = dpp_f64<CTRL, 0xF>(v.hi, 0.0);
+    r.lo = dpp_f64<CTRL, 0xF>(v.lo, 0.0);
+    return r;
+}
+__device__ __forceinline__ DD dd_shfl_xor(DD v, int mask)
+{
+    DD r;
+    r.hi = __shfl_xor(v.hi, mask, kWave);
+    r.lo = __shfl_xor(v.lo, mask, kWave);
+    return r;
+}
+
+// Generic version (any BLOCK): wave tree in six DPP steps (xor 1, xor 2 inside quads; mirror inside 8 and inside 16
+// lanes; row 0->1 and 2->3; rows 0-1 -> rows 2-3) that leave the wave total in lane 63, then one LDS hop and thread 0
+// folds the waves in wave order.  18 double-double merges per wave.
 template <int BLOCK>
-__device__ __forceinline__ Accum block_reduce(Accum a)
+__device__ __forceinline__ Accum block_reduce_generic(Accum a)
 {
     constexpr int NW = BLOCK / kWave;
     __shared__ double s_d[NW][kNumPartDoubles];
@@ -197,6 +228,114 @@ __device__ __forceinline__ Accum block_reduce(Accum a)
     }
     CAVMD_STAMP(3);
     return a;
+}
+
+// 256-thread version: recursive halving.  The three double-double components are treated as four slots {x, y, z, 0}.
+//   xor 1 (quad_perm):  even lanes keep {x, y} and receive the partner's, odd lanes keep {z, 0}      2 merges
+//   xor 2 (quad_perm):  lanes 0/2 of a quad split {x, y}, lanes 1/3 split {z, 0}                      1 merge
+//                       -> lane&3 = 0: x, 1: z, 2: y, 3: nothing; from here on a lane carries ONE component
+//   row_ror:4, row_ror:8 (stay on the same lane&3): every lane holds its component's 16-lane total     2 merges
+//   xor 16, xor 32 (ds_bpermute, 4 dwords each): its 64-lane total                                    2 merges
+// 7 merges instead of 18.  The four waves meet through LDS; lanes 0-15 of wave 0 (lane = 4*wave + slot) finish with
+// the same two row rotations, and thread 0 picks y and z up from lanes 2 and 1 with quad_perm broadcasts.
+// L-typed particles (normally one per system) go through a cheap six-step tree only in waves that saw one.
+// Every step is a fixed permutation, so the result is bit-reproducible.  Returns the block total in thread 0.
+__device__ __forceinline__ Accum block_reduce_256(Accum a)
+{
+    constexpr int NW = 4;
+    __shared__ double s_main[NW][4][2];
+    __shared__ double s_L[NW][3];
+    __shared__ int s_Li[NW][2];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+
+    // L-typed part: only in waves that hold one (wave-uniform branch); result in lane 63
+    if (__any(a.lcnt != 0))
+    {
+#define CAVMD_L_STEP(CTRL, MASK)                                     \
+    a.sx += dpp_f64<CTRL, MASK>(a.sx, 0.0);                          \
+    a.sy += dpp_f64<CTRL, MASK>(a.sy, 0.0);                          \
+    a.sz += dpp_f64<CTRL, MASK>(a.sz, 0.0);                          \
+    a.lmin = min(a.lmin, dpp_i32<CTRL, MASK>(a.lmin, INT_MAX));      \
+    a.lcnt += dpp_i32<CTRL, MASK>(a.lcnt, 0);
+        CAVMD_L_STEP(0xB1, 0xF)
+        CAVMD_L_STEP(0x4E, 0xF)
+        CAVMD_L_STEP(0x141, 0xF)
+        CAVMD_L_STEP(0x140, 0xF)
+        CAVMD_L_STEP(0x142, 0xA)
+        CAVMD_L_STEP(0x143, 0xC)
+#undef CAVMD_L_STEP
+    }
+
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const DD X {a.hx, a.lx}, Y {a.hy, a.ly}, Z {a.hz, a.lz}, W {0.0, 0.0};
+    // xor 1
+    const DD P = dd_sum(dd_sel(b0, Z, X), dd_dpp<0xB1>(dd_sel(b0, X, Z)));
+    const DD Q = dd_sum(dd_sel(b0, W, Y), dd_dpp<0xB1>(dd_sel(b0, Y, W)));
+    // xor 2
+    DD R = dd_sum(dd_sel(b1, Q, P), dd_dpp<0x4E>(dd_sel(b1, P, Q)));
+    // inside the 16-lane row, staying on lane&3
+    R = dd_sum(R, dd_dpp<0x124>(R)); // row_ror:4
+    R = dd_sum(R, dd_dpp<0x128>(R)); // row_ror:8
+    // across rows
+    R = dd_sum(R, dd_shfl_xor(R, 16));
+    R = dd_sum(R, dd_shfl_xor(R, 32));
+    CAVMD_STAMP(2);
+
+    if (lane < 4)
+    {
+        s_main[wave][lane][0] = R.hi;
+        s_main[wave][lane][1] = R.lo;
+    }
+    if (lane == kWave - 1)
+    {
+        s_L[wave][0] = a.sx;
+        s_L[wave][1] = a.sy;
+        s_L[wave][2] = a.sz;
+        s_Li[wave][0] = a.lmin;
+        s_Li[wave][1] = a.lcnt;
+    }
+    __syncthreads();
+    if (wave == 0)
+    {
+        DD T {0.0, 0.0};
+        if (lane < 4 * NW)
+        {
+            T.hi = s_main[lane >> 2][lane & 3][0];
+            T.lo = s_main[lane >> 2][lane & 3][1];
+        }
+        T = dd_sum(T, dd_dpp<0x124>(T));
+        T = dd_sum(T, dd_dpp<0x128>(T)); // lanes 0..3: block totals of x, z, y, (nothing)
+        const DD Tz = dd_dpp<0x55>(T);   // quad_perm [1,1,1,1]
+        const DD Ty = dd_dpp<0xAA>(T);   // quad_perm [2,2,2,2]
+        a.hx = T.hi; a.lx = T.lo;
+        a.hy = Ty.hi; a.ly = Ty.lo;
+        a.hz = Tz.hi; a.lz = Tz.lo;
+        if (lane == 0)
+        {
+            a.sx = s_L[0][0]; a.sy = s_L[0][1]; a.sz = s_L[0][2];
+            a.lmin = s_Li[0][0];
+            a.lcnt = s_Li[0][1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+            {
+                a.sx += s_L[w][0]; a.sy += s_L[w][1]; a.sz += s_L[w][2];
+                a.lmin = min(a.lmin, s_Li[w][0]);
+                a.lcnt += s_Li[w][1];
+            }
+        }
+    }
+    CAVMD_STAMP(3);
+    return a;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ Accum block_reduce(Accum a)
+{
+    if constexpr (BLOCK == 256)
+        return block_reduce_256(a);
+    else
+        return block_reduce_generic<BLOCK>(a);
 }
 
 // ---- input layouts -------------------------------------------------------------------------------
@@ -280,6 +419,16 @@ struct StridedInput
     static __device__ __forceinline__ double y(const Raw& r) { return r.py; }
     static __device__ __forceinline__ double z(const Raw& r) { return r.pz; }
     static __device__ __forceinline__ int tag(const Raw& r) { return r.t; }
+};
+
+// cavmd_params plus the two quotients the formulas need, divided once on the host (IEEE division is correctly rounded
+// on host and device alike, so this changes no bit; it removes two ~150-cycle fp64 divisions from the prologue).
+struct DeviceParams
+{
+    double g;    // couplstr
+    double K;    // phmass * omegac^2
+    double gK;   // g / K            (src/CavityForceCompute.cc:183)
+    double g2K;  // g * g / K        (src/CavityForceCompute.cc:176)
 };
 
 // Where the per-block partials live (SoA so the finalize kernel reads them coalesced).
@@ -435,8 +584,8 @@ struct Scalars
 // bits, which is what lets every block of the fused force map redo it instead of waiting on a separate launch.
 template <class Input, int BLOCK>
 __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in, unsigned N, unsigned nparts, double Lx,
-                                                                double Ly, double Lz, const cavmd_params& prm,
-                                                                const Partials& part)
+                                                                double Ly, double Lz, const DeviceParams& prm,
+                                                                const Partials& part, bool want_energies)
 {
     // Speculative fetch of the last particle: the driver appends the photon last (examples/05_advanced_run.py:
     // 497-505), so this usually removes a dependent memory round trip after the reduction.
@@ -477,7 +626,7 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
     dd_norm(acc.hz, acc.lz);
     double dx = acc.hx, dy = acc.hy, dz = acc.hz;
     const int photon = (acc.lmin == INT_MAX) ? -1 : acc.lmin;
-    const double g = prm.couplstr, K = prm.K;
+    const double g = prm.g, K = prm.K;
     double qx = 0.0, qy = 0.0, qz = 0.0, eh = 0.0, ec = 0.0, ed = 0.0, Dqx = 0.0, Dqy = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     if (threadIdx.x == 0)
     {
@@ -498,14 +647,16 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
                 dy += acc.sy - r.c * qy;
                 dz += acc.sz - r.c * qz;
             }
-            // src/CavityForceCompute.cc:174-176, dot() = a.x*b.x + a.y*b.y + a.z*b.z
-            eh = 0.5 * K * (qx * qx + qy * qy + qz * qz);
-            ec = g * (dx * qx + dy * qy + 0.0 * 0.0);
-            ed = 0.5 * (g * g / K) * (dx * dx + dy * dy + 0.0 * 0.0);
+            if (want_energies)
+            {
+                // src/CavityForceCompute.cc:174-176, dot() = a.x*b.x + a.y*b.y + a.z*b.z
+                eh = 0.5 * K * (qx * qx + qy * qy + qz * qz);
+                ec = g * (dx * qx + dy * qy + 0.0 * 0.0);
+                ed = 0.5 * prm.g2K * (dx * dx + dy * dy + 0.0 * 0.0);
+            }
             // :183
-            const double gK = g / K;
-            Dqx = qx + gK * dx;
-            Dqy = qy + gK * dy;
+            Dqx = qx + prm.gK * dx;
+            Dqy = qy + prm.gK * dy;
             // :203-207
             fx = -K * qx - g * dx;
             fy = -K * qy - g * dy;
@@ -555,10 +706,10 @@ __device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, con
 // ---- kernel 2 (three-launch path): one block publishes the result block ---------------------------------------
 template <class Input, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void finalize_kernel(Input in, unsigned N, unsigned nparts, double Lx, double Ly,
-                                                         double Lz, cavmd_params prm, Partials part, uint64_t sequence,
+                                                         double Lz, DeviceParams prm, Partials part, uint64_t sequence,
                                                          cavmd_result* __restrict__ res)
 {
-    const Scalars sc = reduce_partials_and_finalize<Input, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part);
+    const Scalars sc = reduce_partials_and_finalize<Input, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part, true);
     if (threadIdx.x == 0)
         write_result(res, sc, N, nparts, sequence);
 }
@@ -691,7 +842,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __re
 // publishes the result block; no separate finalize launch and no inter-workgroup hand-off inside the launch.
 template <int BLOCK, int UNROLL, bool NT>
 __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in, unsigned N, unsigned nparts, double Lx,
-                                                                    double Ly, double Lz, cavmd_params prm, int L_typeid,
+                                                                    double Ly, double Lz, DeviceParams prm, int L_typeid,
                                                                     Partials part, uint64_t sequence,
                                                                     cavmd_result* __restrict__ res,
                                                                     v2d* __restrict__ force2)
@@ -711,7 +862,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
                 c_first[u] = in.charge[(base + (size_t)u * BLOCK) >> 1];
         }
     }
-    const Scalars sc = reduce_partials_and_finalize<AosInput, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part);
+    const Scalars sc = reduce_partials_and_finalize<AosInput, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part, blockIdx.x == 0);
     if (threadIdx.x == 0)
     {
         s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
@@ -725,7 +876,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
     m.Dqx = s_m[0]; m.Dqy = s_m[1]; m.Fx = s_m[2]; m.Fy = s_m[3]; m.Fz = s_m[4];
     m.photon = s_mi[0];
     m.nL = s_mi[1];
-    force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.couplstr, L_typeid, force2, c_first);
+    force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.g, L_typeid, force2, c_first);
 }
 
 // ---- kernel 3': force map for the snapshot layout (strided (N,3) force + optional potential energy) ---

@@ -255,16 +255,16 @@ int main(int argc, char** argv)
     V.push_back({"WRITE flat 16B force-array only b256 u4 bpc8 nt", 32.0 * N, [&](int f) {
                      hipLaunchKernelGGL((flat_write_kernel<256, 4, true>), dim3(grid(2 * N, 1024, 8)), dim3(256), 0, st, (v2d*)d_frc[f], 2 * N); }, {}});
     V.push_back({"finalize (2048 partials)", 0.0, [&](int f) {
-                     cavmd_params p; p.omegac = 0.0091; p.couplstr = 1e-3; p.phmass = 1; p.K = 0.0091 * 0.0091;
+                     DeviceParams p; p.g = 1e-3; p.K = 0.0091 * 0.0091; p.gK = p.g / p.K; p.g2K = p.g * p.g / p.K;
                      hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 2048u, L, L, L, p, part, 1ull, d_res); }, {}});
     V.push_back({"finalize (512 partials)", 0.0, [&](int f) {
-                     cavmd_params p; p.omegac = 0.0091; p.couplstr = 1e-3; p.phmass = 1; p.K = 0.0091 * 0.0091;
+                     DeviceParams p; p.g = 1e-3; p.K = 0.0091 * 0.0091; p.gK = p.g / p.K; p.g2K = p.g * p.g / p.K;
                      hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 512u, L, L, L, p, part, 1ull, d_res); }, {}});
 
 
     // ---- whole evaluations: reduce -> finalize -> map on the same frame, as cavmd_compute_hoomd enqueues them ----
     const double B = 92.0 * N;
-    cavmd_params P; P.omegac = 0.0091; P.couplstr = 1e-3; P.phmass = 1; P.K = 0.0091 * 0.0091;
+    DeviceParams P; P.g = 1e-3; P.K = 0.0091 * 0.0091; P.gK = P.g / P.K; P.g2K = P.g * P.g / P.K;
 #define SEQ3(NAME, KB, KU, KP, KNT, KBPC, MB, MU, MNT, MBPC)                                                                \
     V.push_back({NAME, B, [&](int f) {                                                                                  \
                      const unsigned g1 = grid(N, KB * KU, KBPC);                                                        \
