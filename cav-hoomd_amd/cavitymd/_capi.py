@@ -50,7 +50,8 @@ class Result(ctypes.Structure):
                 ("energy", ctypes.c_double * 3), ("photon_force", ctypes.c_double * 3),
                 ("dipole_lo", ctypes.c_double * 3), ("photon_idx", ctypes.c_int32),
                 ("n_photon_typed", ctypes.c_int32), ("n_particles", ctypes.c_uint32),
-                ("n_partials", ctypes.c_uint32), ("sequence", ctypes.c_uint64), ("reserved", ctypes.c_double * 4)]
+                ("n_partials", ctypes.c_uint32), ("sequence", ctypes.c_uint64), ("total_dipole", ctypes.c_double * 3),
+                ("reserved", ctypes.c_double)]
 
 
 # every symbol include/cavmd.h exports; tests check the header and the library against this list

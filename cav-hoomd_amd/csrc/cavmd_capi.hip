@@ -58,7 +58,6 @@ struct cavmd_workspace
     int map_blocks_per_cu = 2;    // every fused block re-folds the partials, so few, long-lived blocks
     int map_nt_store = 0;
     int reduce_nt_load = -1;      // -1 auto, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
-    int reduce_pipeline = 0;      // 1: double-buffered tiles (measured: no gain, 194 VGPRs)
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     // profiling
     bool profiling = false;
@@ -308,37 +307,40 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     int st;
 
     // ---- launch 1: per-block partial sums + photon search
-    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    // Tile depth: 4 particles per lane (1024 per block) when that still gives every CU a block; shallower tiles for
+    // small N so that all 256 CUs take part (at N = 1e5 a 1024-particle tile would occupy 98 CUs).
+    int unroll = kReduceUnroll;
+    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu)
+        unroll >>= 1;
+    const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
     // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
     // by the force map: keeping it temporal lets the map hit it in the Infinity Cache while 8 N bytes are small
     // (measured -4 % per evaluation at N = 1e6) but costs +16 % at N = 1e7, where it only evicts useful lines.
     int nt = ws->reduce_nt_load;
     if (nt < 0)
         nt = (N <= kChargeTemporalMaxN) ? 1 : 2;
-#define CAVMD_LAUNCH_REDUCE(NTMODE, PIPE)                                                                             \
+#define CAVMD_LAUNCH_REDUCE(NTMODE, UNR)                                                                              \
     {                                                                                                                 \
         AosInputT<NTMODE> inx {in.pos2, in.charge, in.image};                                                         \
-        st = ls.launch(0, dipole_partials_kernel<AosInputT<NTMODE>, kReduceBlock, kReduceUnroll, PIPE>, g1,           \
-                       kReduceBlock, inx, n, Lx, Ly, Lz, L_typeid, part);                                             \
+        st = ls.launch(0, dipole_partials_kernel<AosInputT<NTMODE>, kReduceBlock, UNR, false>, g1, kReduceBlock, inx, \
+                       n, Lx, Ly, Lz, L_typeid, part);                                                                \
     }
-    if (ws->reduce_pipeline)
-    {
-        if (nt == 0)
-            CAVMD_LAUNCH_REDUCE(0, true)
-        else if (nt == 1)
-            CAVMD_LAUNCH_REDUCE(1, true)
-        else
-            CAVMD_LAUNCH_REDUCE(2, true)
+#define CAVMD_LAUNCH_REDUCE_NT(UNR)                                                                                   \
+    {                                                                                                                 \
+        if (nt == 0)                                                                                                  \
+            CAVMD_LAUNCH_REDUCE(0, UNR)                                                                               \
+        else if (nt == 1)                                                                                             \
+            CAVMD_LAUNCH_REDUCE(1, UNR)                                                                               \
+        else                                                                                                          \
+            CAVMD_LAUNCH_REDUCE(2, UNR)                                                                               \
     }
+    if (unroll == 4)
+        CAVMD_LAUNCH_REDUCE_NT(4)
+    else if (unroll == 2)
+        CAVMD_LAUNCH_REDUCE_NT(2)
     else
-    {
-        if (nt == 0)
-            CAVMD_LAUNCH_REDUCE(0, false)
-        else if (nt == 1)
-            CAVMD_LAUNCH_REDUCE(1, false)
-        else
-            CAVMD_LAUNCH_REDUCE(2, false)
-    }
+        CAVMD_LAUNCH_REDUCE_NT(1)
+#undef CAVMD_LAUNCH_REDUCE_NT
 #undef CAVMD_LAUNCH_REDUCE
     if (st != CAVMD_OK)
         return st;
@@ -403,6 +405,23 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
         return CAVMD_ERR_CAPACITY;
     if (!params_ok(params))
         return CAVMD_ERR_BAD_PARAMS;
+
+    // HOOMD's GPU local snapshot hands out strided VIEWS of its Scalar4 buffers (position = pos[:, :3], typeid = the
+    // int in pos.w, force = force4[:, :3], potential_energy = force4[:, 3]).  That is exactly the AoS layout, so the
+    // force.Custom route gets the tuned two-launch path.
+    {
+        const char* p0 = reinterpret_cast<const char*>(d_position);
+        const char* f0 = reinterpret_cast<const char*>(d_force);
+        if (position_stride == 32 && typeid_stride == 32 && reinterpret_cast<const char*>(d_typeid) == p0 + 24
+            && image_stride == 12 && charge_stride == 8 && force_stride == 32 && d_potential_energy
+            && potential_energy_stride == 32 && reinterpret_cast<const char*>(d_potential_energy) == f0 + 24
+            && !((uintptr_t)p0 & 15) && !((uintptr_t)f0 & 15))
+        {
+            return cavmd_compute_hoomd(ws, stream_, N, reinterpret_cast<const cavmd_double4*>(d_position), d_charge,
+                                       reinterpret_cast<const cavmd_int3*>(d_image), Lx, Ly, Lz, L_typeid, params,
+                                       reinterpret_cast<cavmd_double4*>(d_force));
+        }
+    }
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
@@ -569,13 +588,6 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->reduce_nt_load = value;
         return CAVMD_OK;
     }
-    if (!strcmp(name, "reduce_pipeline"))
-    {
-        if (value != 0 && value != 1)
-            return CAVMD_ERR_INVALID_VALUE;
-        ws->reduce_pipeline = value;
-        return CAVMD_OK;
-    }
     if (!strcmp(name, "fused_finalize"))
     {
         if (value != 0 && value != 1)
@@ -600,8 +612,6 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->reduce_nt_load;
     else if (!strcmp(name, "fused_finalize"))
         *value = ws->fused_finalize;
-    else if (!strcmp(name, "reduce_pipeline"))
-        *value = ws->reduce_pipeline;
     else
         return CAVMD_ERR_INVALID_VALUE;
     return CAVMD_OK;

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void dipole_partials_kernel(Input in, unsign
 // Everything an evaluation produces besides the per-particle forces, as held by thread 0 of a block.
 struct Scalars
 {
-    double d[3], dlo[3], q[3], Dq[2], e[3], f[3];
+    double d[3], dlo[3], q[3], Dq[2], e[3], f[3], dtot[3];
     int photon, nL;
 };
 
@@ -625,6 +625,10 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
     dd_norm(acc.hy, acc.ly);
     dd_norm(acc.hz, acc.lz);
     double dx = acc.hx, dy = acc.hy, dz = acc.hz;
+    // all particles, L-typed included (the photon normally has charge 0, so this usually equals d)
+    sc.dtot[0] = dx + acc.sx;
+    sc.dtot[1] = dy + acc.sy;
+    sc.dtot[2] = dz + acc.sz;
     const int photon = (acc.lmin == INT_MAX) ? -1 : acc.lmin;
     const double g = prm.g, K = prm.K;
     double qx = 0.0, qy = 0.0, qz = 0.0, eh = 0.0, ec = 0.0, ed = 0.0, Dqx = 0.0, Dqy = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
@@ -692,6 +696,7 @@ __device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, con
         res->energy[k] = sc.e[k];
         res->photon_force[k] = sc.f[k];
         res->dipole_lo[k] = sc.dlo[k];
+        res->total_dipole[k] = sc.dtot[k];
     }
     res->Dq[0] = sc.Dq[0];
     res->Dq[1] = sc.Dq[1];
@@ -700,7 +705,7 @@ __device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, con
     res->n_particles = N;
     res->n_partials = nparts;
     res->sequence = sequence;
-    res->reserved[0] = res->reserved[1] = res->reserved[2] = res->reserved[3] = 0.0;
+    res->reserved = 0.0;
 }
 
 // ---- kernel 2 (three-launch path): one block publishes the result block ---------------------------------------

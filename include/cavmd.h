@@ -108,7 +108,9 @@ typedef struct cavmd_result
     uint32_t n_particles;    /* N of the evaluation this result belongs to */
     uint32_t n_partials;     /* partial sums that fed the final reduction (diagnostic) */
     uint64_t sequence;       /* evaluation counter of the workspace */
-    double reserved[4];
+    double total_dipole[3];  /* sum over ALL particles, L-typed included: what the reference's observable
+                                compute_total_dipole_moment (src/cavitymd/analysis.py:18-31) returns */
+    double reserved;
 } cavmd_result;
 
 typedef struct cavmd_workspace cavmd_workspace; /* opaque */
@@ -196,7 +198,6 @@ CAVMD_API int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* la
  *   "map_blocks_per_cu"    1..16   grid of the force map
  *   "map_nt_store"         0/1     non-temporal force stores
  *   "reduce_nt_load"       -1..2   -1 auto by N, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
- *   "reduce_pipeline"      0/1     double-buffered tiles in the reduction
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
  * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value.  None of them changes results
  * beyond the last bit of the dipole (different but fixed summation trees). */

@@ -46,7 +46,7 @@ def test_layouts_agree_with_header_and_oracle(capi, ref):
     assert ref.layout_sizes()[:3] == (32, 12, 32)
     # offsets the kernels rely on
     assert capi.Result.energy.offset == 64 and capi.Result.photon_idx.offset == 136
-    assert capi.Result.sequence.offset == 152
+    assert capi.Result.sequence.offset == 152 and capi.Result.total_dipole.offset == 160
 
 
 def test_make_params_matches_oracle(capi, ref):

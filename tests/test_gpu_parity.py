@@ -12,6 +12,7 @@ The GPU dipole itself is additionally required to be within 2 ulp of the correct
 """
 import ctypes
 import json
+import math
 import os
 
 import numpy as np
@@ -303,7 +304,7 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     check_parity(cfg, base, refout)
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
                 {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
-                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_pipeline": 1}, {"reduce_pipeline": 1, "reduce_blocks_per_cu": 3}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
+                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
         assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))
@@ -442,6 +443,68 @@ def test_both_layouts_give_identical_bits():
     b = _soa_eval(cfg, hoomd_views=False)
     assert np.array_equal(a["dipole"], b["dipole"]) and np.array_equal(a["energies"], b["energies"])
     assert np.array_equal(a["force"], b["force"])
+
+
+def test_randomised_small_systems_one_workspace(ref, oracle_mod):
+    """200 seeded random systems through ONE workspace and ONE set of device buffers (as a long simulation reuses them):
+    sizes 1..3000, photon anywhere or absent, magnitudes from 1e-150 to 1e+6, zero and negative-zero charges."""
+    cap = 3000
+    ws = _capi.Workspace(cap)
+    dev = "cuda"
+    pos_d = torch.empty((cap, 4), dtype=torch.float64, device=dev)
+    chg_d = torch.empty((cap,), dtype=torch.float64, device=dev)
+    img_d = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    frc_d = torch.empty((cap, 4), dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(2025)
+    for case in range(200):
+        n = int(rng.integers(1, cap + 1))
+        scale = 10.0 ** rng.integers(-3, 7)
+        L = tuple(float(v) for v in scale * rng.uniform(0.5, 2.0, 3))
+        photon_at = int(rng.integers(0, n)) if rng.random() < 0.85 else None
+        cfg = _random_cfg(n, seed=10_000 + case, photon_at=photon_at, L=L, image_range=int(rng.integers(0, 6)))
+        mag = rng.choice([1.0, 1e-150, 1e-8, 1e3])
+        cfg["charge"] = cfg["charge"] * mag
+        zero = rng.random(n) < 0.1
+        cfg["charge"][zero] = np.where(rng.random(zero.sum()) < 0.5, 0.0, -0.0)
+        if photon_at is not None:
+            cfg["charge"][photon_at] = 0.0
+        cfg["params"] = {"omegac": float(10.0 ** rng.uniform(-3, 0)), "couplstr": float(10.0 ** rng.uniform(-4, 0)),
+                         "phmass": float(rng.uniform(0.5, 2.0))}
+        pos_d[:n].copy_(torch.from_numpy(oracle_mod.pack_pos(cfg["position"], cfg["typeid"])))
+        chg_d[:n].copy_(torch.from_numpy(cfg["charge"]))
+        img_d[:n].copy_(torch.from_numpy(cfg["image"]))
+        frc_d.fill_(float("nan"))
+        prm = _capi.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+        ws.compute_hoomd(0, n, pos_d.data_ptr(), chg_d.data_ptr(), img_d.data_ptr(), cfg["box"], 2, prm, frc_d.data_ptr())
+        torch.cuda.synchronize()
+        res = ws.result()
+        gpu = {"force": frc_d[:n].cpu().numpy(), "energies": np.array(ws.energies()), "dipole": np.array(res.dipole[:]),
+               "photon_idx": res.photon_idx}
+        assert np.isnan(frc_d[n:].cpu().numpy()).all(), "wrote past N"
+        check_parity(cfg, gpu, ref_eval(ref, oracle_mod, cfg))
+
+
+# ---- observable that reuses the reduction (SURVEY.md 8f, row f2) ------------------------------------------------------------
+def test_total_dipole_observable(oracle_mod):
+    """cavmd_result.total_dipole = the reference's compute_total_dipole_moment (src/cavitymd/analysis.py:18-31):
+    np.dot(charge, unwrapped_positions) over ALL particles, photon included -- without a snapshot round trip."""
+    for cfg in (_random_cfg(100_000, seed=31, photon_at=99_999, photon_charge=0.0),
+                _random_cfg(77_777, seed=32, photon_at=123, photon_charge=2.5),   # a charged photon counts here
+                _random_cfg(5_000, seed=33)):                                      # no photon at all
+        out = gpu_eval(cfg)
+        unwrapped = cavitymd.unwrap_positions(cfg["position"], cfg["image"], np.asarray(cfg["box"]))
+        want = np.dot(cfg["charge"], unwrapped)          # the reference's expression
+        terms = np.abs(cfg["charge"][:, None] * unwrapped).sum(axis=0)
+        got = np.array(out["result"].total_dipole[:])
+        assert np.all(np.abs(got - want) <= 1e-13 * terms)
+        exact = np.array([math.fsum((cfg["charge"] * unwrapped[:, k]).tolist()) for k in range(3)])
+        # total = fl(d_molecules + c_L r_L): one more rounding, at the size of the larger operand
+        tidL = cfg["typeid"] == cfg["L_typeid"]
+        l_term = np.abs((cfg["charge"][tidL, None] * unwrapped[tidL]).sum(axis=0)) if tidL.any() else np.zeros(3)
+        size = np.maximum(np.abs(exact), l_term)
+        assert np.all(np.abs(got - exact) <= 4 * np.spacing(size) + 1e-300)
+        if out["photon_idx"] < 0:
+            assert not out["dipole"].any() and got.any()   # force-path dipole is zeroed, the observable is not
 
 
 # ---- the user-facing object ---------------------------------------------------------------------------------------------------
