@@ -184,6 +184,25 @@ def side_measurement(cfg, device, frames, steps, warmup):
     return out
 
 
+def density_field_measurement(cfg, device, n_k=50, kmag=1.0, steps=20, warmup=3):
+    """Row f3 side measurement: rho(k) for 50 Fibonacci-sphere wavevectors (the reference tracker's default)."""
+    from cavitymd import observables
+    pd = cavitymd.ParticleData.from_arrays(cfg["position"], cfg["typeid"], cfg["charge"], cfg["image"], cfg["types"],
+                                           cfg["box"], device=device)
+    field = observables.DensityField(pd, observables.generate_fibonacci_sphere(n_k) * kmag)
+    for _ in range(warmup):
+        field.enqueue()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        field.enqueue()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    n = pd.getN()
+    return {"N": n, "n_k": n_k, "us_per_call": 1e6 * t, "sincos_per_s": n * n_k / t,
+            "note": "fp64 transcendental bound: N*n_k sincos per call; positions are only 32 N bytes"}
+
+
 def main():
     args = parse_args()
     ctx = replicas.init_from_env(prefer_gpu=True)
@@ -248,6 +267,7 @@ def main():
             extras["1e5_cache_hot"] = side_measurement(synthetic.config2(), ctx.device, 1, 300, 30)
             extras["1e5_ring"] = side_measurement(synthetic.config2(), ctx.device, 64, 300, 30)
             extras["1e7_hbm"] = side_measurement(synthetic.config4(), ctx.device, 2, 50, 5)
+            extras["density_field_1e6_50k"] = density_field_measurement(cfg, ctx.device)
             line["extras"] = extras
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)

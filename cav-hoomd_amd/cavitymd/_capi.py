@@ -57,7 +57,8 @@ class Result(ctypes.Structure):
 # every symbol include/cavmd.h exports; tests check the header and the library against this list
 EXPORTED_SYMBOLS = (
     "cavmd_make_params", "cavmd_create", "cavmd_destroy", "cavmd_compute_hoomd", "cavmd_compute_soa",
-    "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_profile_enable", "cavmd_profile_read",
+    "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_set_wavevectors", "cavmd_density_field",
+    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_profile_enable", "cavmd_profile_read",
     "cavmd_set_tunable", "cavmd_get_tunable", "cavmd_device_info", "cavmd_error_string", "cavmd_version",
 )
 
@@ -105,6 +106,14 @@ def load():
         lib.cavmd_result_read.restype = ci
         lib.cavmd_result_device_ptr.argtypes = [vp, P(vp)]
         lib.cavmd_result_device_ptr.restype = ci
+        lib.cavmd_set_wavevectors.argtypes = [vp, sz, vp]
+        lib.cavmd_set_wavevectors.restype = ci
+        lib.cavmd_density_field.argtypes = [vp, vp, sz, vp, sz]
+        lib.cavmd_density_field.restype = ci
+        lib.cavmd_density_field_read.argtypes = [vp, vp]
+        lib.cavmd_density_field_read.restype = ci
+        lib.cavmd_cavity_mode.argtypes = [vp, vp, vp, dbl, P(dbl * 4)]
+        lib.cavmd_cavity_mode.restype = ci
         lib.cavmd_profile_enable.argtypes = [vp, ci]
         lib.cavmd_profile_enable.restype = ci
         lib.cavmd_profile_read.argtypes = [vp, P(dbl * 3), P(ctypes.c_uint64)]
@@ -196,6 +205,31 @@ class Workspace:
         p = ctypes.c_void_p()
         check(self._lib.cavmd_result_device_ptr(self._h, ctypes.byref(p)), "cavmd_result_device_ptr")
         return int(p.value)
+
+    # -- observables -----------------------------------------------------
+    def set_wavevectors(self, wavevectors) -> None:
+        import numpy as np
+        k = np.ascontiguousarray(wavevectors, dtype=np.float64)
+        if k.ndim != 2 or k.shape[1] != 3:
+            raise ValueError("wavevectors must have shape (n_k, 3)")
+        self._n_k = int(k.shape[0])
+        check(self._lib.cavmd_set_wavevectors(self._h, self._n_k, ctypes.c_void_p(k.ctypes.data)), "cavmd_set_wavevectors")
+
+    def density_field(self, stream: int, N: int, position_ptr: int, position_stride: int) -> None:
+        check(self._lib.cavmd_density_field(self._h, ctypes.c_void_p(stream), int(N), ctypes.c_void_p(position_ptr),
+                                            int(position_stride)), "cavmd_density_field")
+
+    def density_field_read(self):
+        import numpy as np
+        out = np.empty(2 * self._n_k, dtype=np.float64)
+        check(self._lib.cavmd_density_field_read(self._h, ctypes.c_void_p(out.ctypes.data)), "cavmd_density_field_read")
+        return out[0::2] + 1j * out[1::2]
+
+    def cavity_mode(self, stream: int, vel_ptr: int, kB: float):
+        out = (ctypes.c_double * 4)()
+        check(self._lib.cavmd_cavity_mode(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr), float(kB),
+                                          ctypes.byref(out)), "cavmd_cavity_mode")
+        return float(out[0]), float(out[1]), float(out[2]), float(out[3])
 
     # -- measurement / tuning -----------------------------------------------------------------------
     def profile_enable(self, on: bool) -> None:

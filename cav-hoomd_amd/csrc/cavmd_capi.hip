@@ -66,6 +66,18 @@ struct cavmd_workspace
     std::vector<unsigned> slot_mask; // which of the three kernels a slot's evaluation launched
     double acc_ms[3] = {0, 0, 0};
     uint64_t acc_launches = 0;
+    // observables (rows f2 / f3)
+    size_t n_k = 0;
+    unsigned n_chunks = 0;
+    unsigned rho_blocks = 0;
+    double* d_kvec = nullptr;
+    double* d_rho_part = nullptr;
+    double* d_rho = nullptr;
+    double* h_rho = nullptr; // pinned
+    hipStream_t rho_stream = nullptr;
+    bool rho_computed = false;
+    double* d_mode = nullptr;
+    double* h_mode = nullptr; // pinned
 };
 
 namespace
@@ -271,6 +283,18 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipFree(ws->d_result);
     if (ws->h_result)
         (void)hipHostFree(ws->h_result);
+    if (ws->d_kvec)
+        (void)hipFree(ws->d_kvec);
+    if (ws->d_rho_part)
+        (void)hipFree(ws->d_rho_part);
+    if (ws->d_rho)
+        (void)hipFree(ws->d_rho);
+    if (ws->h_rho)
+        (void)hipHostFree(ws->h_rho);
+    if (ws->d_mode)
+        (void)hipFree(ws->d_mode);
+    if (ws->h_mode)
+        (void)hipHostFree(ws->h_mode);
     delete ws;
     return CAVMD_OK;
 }
@@ -504,6 +528,97 @@ int cavmd_result_device_ptr(cavmd_workspace* ws, const cavmd_result** out)
     if (!ws || !out)
         return CAVMD_ERR_INVALID_VALUE;
     *out = ws->d_result;
+    return CAVMD_OK;
+}
+
+int cavmd_set_wavevectors(cavmd_workspace* ws, size_t n_k, const double* h_wavevectors)
+{
+    if (!ws || !h_wavevectors || n_k == 0 || n_k > (size_t)1 << 20)
+        return CAVMD_ERR_INVALID_VALUE;
+    DeviceGuard guard(ws->device);
+    if (ws->d_kvec)
+        (void)hipFree(ws->d_kvec);
+    if (ws->d_rho_part)
+        (void)hipFree(ws->d_rho_part);
+    if (ws->d_rho)
+        (void)hipFree(ws->d_rho);
+    if (ws->h_rho)
+        (void)hipHostFree(ws->h_rho);
+    ws->d_kvec = ws->d_rho_part = ws->d_rho = ws->h_rho = nullptr;
+    ws->rho_computed = false;
+    ws->n_k = n_k;
+    ws->n_chunks = (unsigned)((n_k + kWave - 1) / kWave);
+    ws->rho_blocks = (unsigned)(ws->num_cu * 4); // 4 blocks of 4 waves per CU: 16 of the 32 wave slots, all SIMDs busy
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_kvec, sizeof(double) * 3 * n_k));
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho_part, sizeof(double) * 2 * kWave * (size_t)ws->n_chunks * ws->rho_blocks));
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho, sizeof(double) * 2 * n_k));
+    CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_rho, sizeof(double) * 2 * n_k, hipHostMallocDefault));
+    CAVMD_HIP_TRY(hipMemcpy(ws->d_kvec, h_wavevectors, sizeof(double) * 3 * n_k, hipMemcpyHostToDevice));
+    return CAVMD_OK;
+}
+
+int cavmd_density_field(cavmd_workspace* ws, void* stream_, size_t N, const double* d_position, size_t position_stride)
+{
+    if (!ws || !d_position || position_stride < 24 || (position_stride & 7) || ((uintptr_t)d_position & 7))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (ws->n_k == 0)
+        return CAVMD_ERR_NOT_COMPUTED; // no wavevectors stored yet
+    if (N > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    constexpr int kBlock = 256;
+    const size_t tiles = (N + kWave - 1) / kWave;
+    size_t gb = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+    if (gb > ws->rho_blocks)
+        gb = ws->rho_blocks;
+    if (gb == 0)
+        gb = 1;
+    hipLaunchKernelGGL((density_partials_kernel<kBlock>), dim3((unsigned)gb, ws->n_chunks), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const char*>(d_position), position_stride, (unsigned)N, ws->d_kvec,
+                       (unsigned)ws->n_k, ws->d_rho_part);
+    CAVMD_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((density_fold_kernel<kBlock>), dim3(ws->n_chunks), dim3(kBlock), 0, stream, ws->d_rho_part,
+                       (unsigned)gb, (unsigned)ws->n_k, ws->d_rho);
+    CAVMD_HIP_TRY(hipGetLastError());
+    ws->rho_stream = stream;
+    ws->rho_computed = true;
+    return CAVMD_OK;
+}
+
+int cavmd_density_field_read(cavmd_workspace* ws, double* h_out)
+{
+    if (!ws || !h_out)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!ws->rho_computed)
+        return CAVMD_ERR_NOT_COMPUTED;
+    DeviceGuard guard(ws->device);
+    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_rho, ws->d_rho, sizeof(double) * 2 * ws->n_k, hipMemcpyDeviceToHost, ws->rho_stream));
+    CAVMD_HIP_TRY(hipStreamSynchronize(ws->rho_stream));
+    memcpy(h_out, ws->h_rho, sizeof(double) * 2 * ws->n_k);
+    return CAVMD_OK;
+}
+
+int cavmd_cavity_mode(cavmd_workspace* ws, void* stream_, const cavmd_double4* d_vel, double kB, double out[4])
+{
+    if (!ws || !d_vel || !out || !(kB > 0.0) || ((uintptr_t)d_vel & 15))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!ws->computed)
+        return CAVMD_ERR_NOT_COMPUTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    if (!ws->d_mode)
+    {
+        CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_mode, sizeof(double) * 4));
+        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_mode, sizeof(double) * 4, hipHostMallocDefault));
+    }
+    const cavmd_result* res = ws->d_result;
+    hipLaunchKernelGGL(cavity_mode_kernel, dim3(1), dim3(1), 0, stream, res, d_vel, kB, ws->d_mode);
+    CAVMD_HIP_TRY(hipGetLastError());
+    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_mode, ws->d_mode, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
+    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < 4; ++k)
+        out[k] = ws->h_mode[k];
     return CAVMD_OK;
 }
 

@@ -931,3 +931,179 @@ __global__ __launch_bounds__(BLOCK) void force_map_strided_kernel(StridedInput i
 }
 
 } // namespace cavmd
+
+// =====================================================================================================================
+// Observable next to the force path: density field rho(k) = sum_j exp(i k.r_j) over the WRAPPED
+// positions of all particles, for a set of wavevectors (reference: compute_density_field, src/cavitymd/analysis.py:34-47,
+// a Python loop over 50 wavevectors of numpy cos/sin over all particles).
+//
+// Mapping: LANE = WAVEVECTOR.  A wave loads 64 particles' positions with one coalesced round (lane = particle), then
+// walks them one by one: the particle's coordinates are broadcast with v_readlane (SGPR operands), every lane forms
+// k_lane . r = (x kx + y ky) + z kz and adds cos / sin to its own two accumulators.  The particle loop therefore has no
+// cross-lane traffic and no per-lane register pressure (2 accumulators), whatever the number of wavevectors; more than
+// 64 wavevectors are handled in chunks of 64 (blockIdx.y).  The kernel is bound by fp64 transcendental throughput
+// (~N * n_k sincos), not by memory: positions are 24 N bytes per chunk.
+// =====================================================================================================================
+namespace cavmd
+{
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sin and cos of one argument for |x| < 1e8: n = rint(x * 2/pi), r = x - n * pi/2 by a two-constant Cody-Waite step
+// with explicit FMAs (pi/2 = P1 + P2 to 107 bits; error ~1 ulp of r for |n| < 2^27), then the fdlibm kernel
+// polynomials on |r| <= pi/4 (S1..S6, C1..C6 of __kernel_sin / __kernel_cos, < 1 ulp each) and the quadrant swap.
+// ~27 fp64 operations against ~100 for the device library's sincos, whose Payne-Hanek path is kept for huge arguments.
+__device__ __forceinline__ void sincos_reduced(double x, double& s, double& c)
+{
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01); // 2/pi
+    double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);     // P1 = double(pi/2)
+    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);            // P2 = pi/2 - P1
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(z * r, ps, r);
+    // cos(r) = 1 - (z/2 - z^2 (C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6))))))
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = 1.0 - __builtin_fma(-z * z, pc, 0.5 * z);
+    const int q = (int)n;
+    const double ss = (q & 1) ? cr : sr;
+    const double cc = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// part layout: [chunk][block][2][64] doubles
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __restrict__ pos, size_t pos_stride, unsigned N,
+                                                                 const double* __restrict__ kvec, unsigned n_k,
+                                                                 double* __restrict__ part)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_acc[NW][2][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const unsigned chunk = blockIdx.y;
+    const unsigned k = chunk * kWave + lane;
+    const bool active = k < n_k;
+    const double kx = active ? kvec[3 * k + 0] : 0.0;
+    const double ky = active ? kvec[3 * k + 1] : 0.0;
+    const double kz = active ? kvec[3 * k + 2] : 0.0;
+
+    double re = 0.0, im = 0.0;
+    const unsigned ntiles = (N + kWave - 1) / kWave;
+    const unsigned gw = blockIdx.x * NW + wave, GW = gridDim.x * NW;
+    for (unsigned tile = gw; tile < ntiles; tile += GW)
+    {
+        const size_t i = (size_t)tile * kWave + lane;
+        double px = 0.0, py = 0.0, pz = 0.0;
+        if (i < N)
+        {
+            const double* p = reinterpret_cast<const double*>(pos + i * pos_stride);
+            px = p[0];
+            py = p[1];
+            pz = p[2];
+        }
+        const unsigned left = N - tile * kWave;
+        const int cnt = left < (unsigned)kWave ? (int)left : kWave; // wave-uniform
+        for (int j = 0; j < cnt; ++j)
+        {
+            const double x = readlane_f64(px, j), y = readlane_f64(py, j), z = readlane_f64(pz, j);
+            const double kr = (x * kx + y * ky) + z * kz;
+            double s, c;
+            if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
+                sincos(kr, &s, &c);
+            else
+                sincos_reduced(kr, s, c);
+            re += c;
+            im += s;
+        }
+    }
+    s_acc[wave][0][lane] = re;
+    s_acc[wave][1][lane] = im;
+    __syncthreads();
+    if (wave == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+        {
+            re += s_acc[w][0][lane];
+            im += s_acc[w][1][lane];
+        }
+        double* out = part + ((size_t)chunk * gridDim.x + blockIdx.x) * 2 * kWave;
+        out[lane] = re;
+        out[kWave + lane] = im;
+    }
+}
+
+// one block per chunk of 64 wavevectors: thread (w, lane) folds blocks w, w+NW, ... of wavevector `lane` with TwoSum,
+// the NW waves meet in LDS.  out: interleaved (re, im) per wavevector.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void density_fold_kernel(const double* __restrict__ part, unsigned nblocks, unsigned n_k,
+                                                             double* __restrict__ out)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_acc[NW][4][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const unsigned chunk = blockIdx.x;
+    double rh = 0.0, rl = 0.0, ih = 0.0, il = 0.0;
+    for (unsigned b = wave; b < nblocks; b += NW)
+    {
+        const double* p = part + ((size_t)chunk * nblocks + b) * 2 * kWave;
+        dd_acc(rh, rl, p[lane]);
+        dd_acc(ih, il, p[kWave + lane]);
+    }
+    s_acc[wave][0][lane] = rh; s_acc[wave][1][lane] = rl;
+    s_acc[wave][2][lane] = ih; s_acc[wave][3][lane] = il;
+    __syncthreads();
+    if (wave == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+        {
+            dd_merge(rh, rl, s_acc[w][0][lane], s_acc[w][1][lane]);
+            dd_merge(ih, il, s_acc[w][2][lane], s_acc[w][3][lane]);
+        }
+        const unsigned k = chunk * kWave + lane;
+        if (k < n_k)
+        {
+            out[2 * k] = rh + rl;
+            out[2 * k + 1] = ih + il;
+        }
+    }
+}
+
+// Cavity-mode kinetic energy (reference: CavityModeTracker.compute_cavity_properties, src/cavitymd/analysis.py:1324-1368):
+// KE = 1/2 m v.v of the photon found by the last force evaluation; HOOMD keeps the mass in vel.w.
+// out[0..3] = KE, harmonic PE (from the result block), KE + PE, temperature = (2/3) KE / k_B.
+__global__ void cavity_mode_kernel(const cavmd_result* __restrict__ res, const cavmd_double4* __restrict__ vel, double kB,
+                                   double* __restrict__ out)
+{
+    const int p = res->photon_idx;
+    double ke = 0.0, pe = 0.0, tot = 0.0, temp = 0.0;
+    if (p >= 0)
+    {
+        const cavmd_double4 v = vel[p];
+        ke = 0.5 * v.w * ((v.x * v.x + v.y * v.y) + v.z * v.z);
+        pe = res->energy[0];
+        tot = ke + pe;
+        temp = (2.0 / 3.0) * ke / kB;
+    }
+    out[0] = ke;
+    out[1] = pe;
+    out[2] = tot;
+    out[3] = temp;
+}
+} // namespace cavmd

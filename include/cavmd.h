@@ -183,6 +183,24 @@ CAVMD_API int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out);
 /* Device address of the result block, for consumers that stay on the GPU (trackers, graphs). */
 CAVMD_API int cavmd_result_device_ptr(cavmd_workspace* ws, const cavmd_result** out);
 
+/* ---- observables next to the force path ------------------------------------------- */
+/* Wavevectors for the density field: n_k rows of (kx, ky, kz) in HOST memory; copied into the workspace once.
+ * The reference builds them as kmag * generate_fibonacci_sphere(50) (src/cavitymd/analysis.py:296-306). */
+CAVMD_API int cavmd_set_wavevectors(cavmd_workspace* ws, size_t n_k, const double* h_wavevectors);
+/* rho(k) = sum_j exp(i k . r_j) over the WRAPPED positions of all N particles, for every stored wavevector;
+ * replaces compute_density_field (src/cavitymd/analysis.py:34-47), which pulls a CPU snapshot and loops in numpy.
+ * d_position + i * position_stride points at particle i's x, y, z (stride 32 for HOOMD's Scalar4 pos, 24 for a
+ * packed (N,3) array).  Enqueues two kernels on `stream`; no host synchronisation. */
+CAVMD_API int cavmd_density_field(cavmd_workspace* ws, void* stream, size_t N, const double* d_position,
+                                  size_t position_stride);
+/* Copies the last density field out: h_out[2k] = Re rho(k_k), h_out[2k+1] = Im rho(k_k).  Synchronises the stream. */
+CAVMD_API int cavmd_density_field_read(cavmd_workspace* ws, double* h_out);
+/* Cavity-mode properties of CavityModeTracker (src/cavitymd/analysis.py:1324-1368) for the photon the last force
+ * evaluation found: out = {KE = 1/2 m v.v, harmonic PE, KE + PE, T = (2/3) KE / k_B}; all zero without a photon.
+ * d_vel is HOOMD's Scalar4 velocity array (mass in .w); kB in Hartree/K (the reference uses 3.167e-6).
+ * Enqueues one tiny kernel and a 32-byte copy on `stream` and waits for them. */
+CAVMD_API int cavmd_cavity_mode(cavmd_workspace* ws, void* stream, const cavmd_double4* d_vel, double kB, double out[4]);
+
 /* ---- measurement hooks (bench.py's roofline leg) ---------------------------------------------- */
 /* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */
 CAVMD_API int cavmd_profile_enable(cavmd_workspace* ws, int on);
