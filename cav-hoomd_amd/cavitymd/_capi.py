@@ -58,7 +58,7 @@ class Result(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "cavmd_make_params", "cavmd_create", "cavmd_destroy", "cavmd_compute_hoomd", "cavmd_compute_soa",
     "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_set_wavevectors", "cavmd_density_field",
-    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_profile_enable", "cavmd_profile_read",
+    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_profile_enable", "cavmd_profile_read",
     "cavmd_set_tunable", "cavmd_get_tunable", "cavmd_device_info", "cavmd_error_string", "cavmd_version",
 )
 
@@ -114,6 +114,8 @@ def load():
         lib.cavmd_density_field_read.restype = ci
         lib.cavmd_cavity_mode.argtypes = [vp, vp, vp, dbl, P(dbl * 4)]
         lib.cavmd_cavity_mode.restype = ci
+        lib.cavmd_force_mass_sum.argtypes = [vp, vp, sz, vp, vp, P(dbl)]
+        lib.cavmd_force_mass_sum.restype = ci
         lib.cavmd_profile_enable.argtypes = [vp, ci]
         lib.cavmd_profile_enable.restype = ci
         lib.cavmd_profile_read.argtypes = [vp, P(dbl * 3), P(ctypes.c_uint64)]
@@ -230,6 +232,12 @@ class Workspace:
         check(self._lib.cavmd_cavity_mode(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr), float(kB),
                                           ctypes.byref(out)), "cavmd_cavity_mode")
         return float(out[0]), float(out[1]), float(out[2]), float(out[3])
+
+    def force_mass_sum(self, stream: int, N: int, force_ptr: int, vel_ptr: int) -> float:
+        out = ctypes.c_double()
+        check(self._lib.cavmd_force_mass_sum(self._h, ctypes.c_void_p(stream), int(N), ctypes.c_void_p(force_ptr),
+                                             ctypes.c_void_p(vel_ptr), ctypes.byref(out)), "cavmd_force_mass_sum")
+        return float(out.value)
 
     # -- measurement / tuning -----------------------------------------------------------------------
     def profile_enable(self, on: bool) -> None:

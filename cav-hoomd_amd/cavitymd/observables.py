@@ -7,6 +7,8 @@ Names follow the reference's observable library (src/cavitymd/analysis.py:14-64)
     compute_total_dipole_moment(compute)               sum_i q_i r_i over ALL particles, from the force's own reduction
     DensityField(pdata, wavevectors).compute()         rho(k) = sum_j exp(i k . r_j), wrapped positions, all particles
     cavity_mode(compute, velocity)                     (KE, harmonic PE, KE + PE, T) of the cavity oscillator
+    force_mass_sum(workspace, net_force, velocity)     sum_i |F_i| / m_i, what AdaptiveTimestepUpdater reduces on the host
+    adaptive_timestep(error_tolerance, S)              dt = sqrt(tol / S)   (src/cavitymd/simulation.py:88-91)
 """
 from __future__ import annotations
 
@@ -72,3 +74,23 @@ def cavity_mode(compute, velocity: torch.Tensor, stream=None):
         stream = torch.cuda.current_stream(velocity.device)
     handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
     return compute.workspace.cavity_mode(handle, velocity.data_ptr(), PhysicalConstants.KB_HARTREE_PER_K)
+
+
+def force_mass_sum(workspace: _capi.Workspace, net_force: torch.Tensor, velocity: torch.Tensor, stream=None) -> float:
+    """S = sum_i |F_i| / m_i over HOOMD's (N,4) net-force and velocity arrays (mass = velocity[:, 3]) on the GPU."""
+    for name, t in (("net_force", net_force), ("velocity", velocity)):
+        if t.dtype != torch.float64 or t.dim() != 2 or t.shape[1] != 4 or not t.is_contiguous():
+            raise ValueError(f"{name} must be a contiguous (N,4) float64 tensor (HOOMD Scalar4)")
+    if net_force.shape[0] != velocity.shape[0]:
+        raise ValueError("net_force and velocity disagree on N")
+    if stream is None:
+        stream = torch.cuda.current_stream(net_force.device)
+    handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    return workspace.force_mass_sum(handle, net_force.shape[0], net_force.data_ptr(), velocity.data_ptr())
+
+
+def adaptive_timestep(error_tolerance: float, force_mass_sum_value: float):
+    """dt = sqrt(tol / S); None when S == 0 (the reference then leaves dt unchanged, simulation.py:88)."""
+    if not force_mass_sum_value > 0:
+        return None
+    return math.sqrt(error_tolerance / force_mass_sum_value)

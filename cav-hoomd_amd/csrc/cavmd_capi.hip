@@ -78,6 +78,8 @@ struct cavmd_workspace
     bool rho_computed = false;
     double* d_mode = nullptr;
     double* h_mode = nullptr; // pinned
+    double* d_fm_part = nullptr; // [2][max_parts] + 1 result
+    double* h_fm = nullptr;      // pinned
 };
 
 namespace
@@ -295,6 +297,10 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipFree(ws->d_mode);
     if (ws->h_mode)
         (void)hipHostFree(ws->h_mode);
+    if (ws->d_fm_part)
+        (void)hipFree(ws->d_fm_part);
+    if (ws->h_fm)
+        (void)hipHostFree(ws->h_fm);
     delete ws;
     return CAVMD_OK;
 }
@@ -619,6 +625,40 @@ int cavmd_cavity_mode(cavmd_workspace* ws, void* stream_, const cavmd_double4* d
     CAVMD_HIP_TRY(hipStreamSynchronize(stream));
     for (int k = 0; k < 4; ++k)
         out[k] = ws->h_mode[k];
+    return CAVMD_OK;
+}
+
+int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream_, size_t N, const cavmd_double4* d_net_force,
+                         const cavmd_double4* d_vel, double* out)
+{
+    if (!ws || !d_net_force || !d_vel || !out || ((uintptr_t)d_net_force & 15) || ((uintptr_t)d_vel & 15))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (N > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY;
+    if (N == 0)
+    {
+        *out = 0.0;
+        return CAVMD_OK;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    if (!ws->d_fm_part)
+    {
+        CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_part, sizeof(double) * (2 * (size_t)ws->max_parts + 1)));
+        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_fm, sizeof(double), hipHostMallocDefault));
+    }
+    constexpr int kBlock = 256, kUnroll = 4;
+    const unsigned g = grid_for(N, kBlock * kUnroll, ws->num_cu, 4);
+    double* d_out = ws->d_fm_part + 2 * (size_t)ws->max_parts;
+    hipLaunchKernelGGL((force_mass_partials_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const v2d*>(d_net_force), reinterpret_cast<const v2d*>(d_vel), (unsigned)N,
+                       ws->d_fm_part);
+    CAVMD_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((force_mass_fold_kernel<kBlock>), dim3(1), dim3(kBlock), 0, stream, ws->d_fm_part, g, d_out);
+    CAVMD_HIP_TRY(hipGetLastError());
+    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_fm, d_out, sizeof(double), hipMemcpyDeviceToHost, stream));
+    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
+    *out = *ws->h_fm;
     return CAVMD_OK;
 }
 

@@ -1107,3 +1107,91 @@ __global__ void cavity_mode_kernel(const cavmd_result* __restrict__ res, const c
     out[3] = temp;
 }
 } // namespace cavmd
+
+// =====================================================================================================================
+// Row f4 (data-parallel part): S = sum_i |F_i| / m_i over the net force, the quantity AdaptiveTimestepUpdater turns into
+// dt = sqrt(tol / S) (reference: src/cavitymd/simulation.py:66-92, via a host snapshot and a Python list comprehension).
+// One streaming pass over the Scalar4 net-force array and the Scalar4 velocity array (HOOMD keeps the mass in vel.w):
+// 64 B of lines per particle, 40 B algorithmic.  Same fixed-order compensated tree as the dipole.
+// =====================================================================================================================
+namespace cavmd
+{
+// six-step DPP wave tree + LDS fold for ONE double-double value; total in thread 0
+template <int BLOCK>
+__device__ __forceinline__ DD block_reduce_dd1(DD v)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_v[NW][2];
+    v = dd_sum(v, dd_dpp<0xB1>(v));
+    v = dd_sum(v, dd_dpp<0x4E>(v));
+    v = dd_sum(v, dd_dpp<0x124>(v));
+    v = dd_sum(v, dd_dpp<0x128>(v));
+    v = dd_sum(v, dd_shfl_xor(v, 16));
+    v = dd_sum(v, dd_shfl_xor(v, 32));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    if (lane == 0)
+    {
+        s_v[wave][0] = v.hi;
+        s_v[wave][1] = v.lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+            dd_merge(v.hi, v.lo, s_v[w][0], s_v[w][1]);
+    }
+    return v;
+}
+
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void force_mass_partials_kernel(const v2d* __restrict__ force2,
+                                                                    const v2d* __restrict__ vel2, unsigned N,
+                                                                    double* __restrict__ part /* [2][gridDim] */)
+{
+    constexpr unsigned TILE = BLOCK * UNROLL;
+    DD acc {0.0, 0.0};
+    const unsigned tiles = (N + TILE - 1) / TILE;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
+    {
+        const size_t base = (size_t)t * TILE + threadIdx.x;
+        v2d fxy[UNROLL], fzw[UNROLL], vzw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const size_t i = base + (size_t)u * BLOCK;
+            const bool ok = i < N;
+            const v2d zero = {0.0, 0.0}, one = {0.0, 1.0};
+            fxy[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i) : zero;
+            fzw[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i + 1) : zero;
+            vzw[u] = ok ? __builtin_nontemporal_load(vel2 + 2 * i + 1) : one;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const double n2 = (fxy[u].x * fxy[u].x + fxy[u].y * fxy[u].y) + fzw[u].x * fzw[u].x;
+            dd_acc(acc.hi, acc.lo, sqrt(n2) / vzw[u].y); // |F_i| / m_i; padding lanes add 0 / 1
+        }
+    }
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+    {
+        part[blockIdx.x] = acc.hi;
+        part[gridDim.x + blockIdx.x] = acc.lo;
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void force_mass_fold_kernel(const double* __restrict__ part, unsigned nparts,
+                                                                double* __restrict__ out)
+{
+    DD acc {0.0, 0.0};
+    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
+        dd_merge(acc.hi, acc.lo, part[p], part[nparts + p]);
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+        out[0] = acc.hi + acc.lo;
+}
+} // namespace cavmd

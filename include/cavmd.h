@@ -201,6 +201,12 @@ CAVMD_API int cavmd_density_field_read(cavmd_workspace* ws, double* h_out);
  * Enqueues one tiny kernel and a 32-byte copy on `stream` and waits for them. */
 CAVMD_API int cavmd_cavity_mode(cavmd_workspace* ws, void* stream, const cavmd_double4* d_vel, double kB, double out[4]);
 
+/* S = sum_i |F_i| / m_i over a Scalar4 net-force array and HOOMD's Scalar4 velocity array (mass in .w): the reduction
+ * AdaptiveTimestepUpdater performs on the host every step to set dt = sqrt(tol / S) (src/cavitymd/simulation.py:66-92).
+ * Enqueues two kernels and an 8-byte copy on `stream` and waits for them (the caller needs the number to set dt). */
+CAVMD_API int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream, size_t N, const cavmd_double4* d_net_force,
+                                   const cavmd_double4* d_vel, double* out);
+
 /* ---- measurement hooks (bench.py's roofline leg) ---------------------------------------------- */
 /* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */
 CAVMD_API int cavmd_profile_enable(cavmd_workspace* ws, int on);

@@ -10,6 +10,8 @@ at module top; the functions below are plain numpy and are restated one for one)
     cavity mode properties        analysis.py:1324-1368 KE = 1/2 m v.v of the photon, T = (2/3) KE / k_B,
                                                         PE = the force's harmonic energy
 
+    adaptive-dt reduction         simulation.py:66-92   sum_i |f_i| / m_i, dt = sqrt(tol / sum)
+
 Pinning status: the reference has no tests for these either -> unpinned by reference fixtures; pinned here by closed-form
 cases (tests/test_oracle_observables.py).
 """
@@ -75,3 +77,16 @@ def cavity_mode(velocity, mass, typeid, harmonic_energy: float, L_typeid: int = 
     ke = 0.5 * m * np.sum(v**2)
     total = ke + harmonic_energy
     return float(ke), float(harmonic_energy), float(total), float((2.0 / 3.0) * ke / KB_HARTREE_PER_K)
+
+
+def force_mass_sum(total_forces, masses) -> float:
+    """sum_i |f_i| / m_i exactly as AdaptiveTimestepUpdater.act spells it (simulation.py:84-86)."""
+    total_forces = np.asarray(total_forces, dtype=np.float64)
+    force_norm = np.array([np.linalg.norm(f) for f in total_forces])
+    return float(np.sum(force_norm / np.asarray(masses, dtype=np.float64)))
+
+
+def force_mass_sum_exact(total_forces, masses) -> float:
+    f = np.asarray(total_forces, dtype=np.float64)
+    n = np.sqrt((f[:, 0] * f[:, 0] + f[:, 1] * f[:, 1]) + f[:, 2] * f[:, 2])
+    return math.fsum((n / np.asarray(masses, dtype=np.float64)).tolist())

@@ -124,7 +124,7 @@ def check_parity(cfg, gpu, refout, tol=1e-10):
     raw_rel = diff[mol, :2] / (np.abs(refout["force"][mol, :2]) + 1e-300)
     return {"max_scaled_force_err": float((diff / (S[:, None] + 1e-300)).max()),
             "max_raw_rel_force_err": float(raw_rel.max()) if raw_rel.size else 0.0,
-            "dipole_rel_err_vs_ref": float(np.abs(d_gpu - d_ref).max() / np.abs(d_ref).max())}
+            "dipole_rel_err_vs_ref": float(np.abs(d_gpu - d_ref).max() / max(np.abs(d_ref).max(), 1e-300))}
 
 
 # ---- known answers and golden vectors ----------------------------------------------------------------------------

@@ -43,3 +43,10 @@ def test_total_dipole_and_cavity_mode():
     ke, pe, tot, T = obs.cavity_mode(np.array([[0, 0, 0], [1.0, 2.0, 2.0]]), np.array([1.0, 0.5]), np.array([0, 2]), 0.125)
     assert (ke, pe, tot) == (0.5 * 0.5 * 9.0, 0.125, 2.375) and T == (2.0 / 3.0) * 2.25 / 3.167e-6
     assert obs.cavity_mode(np.zeros((2, 3)), np.ones(2), np.array([0, 1]), 1.0) == (0.0, 0.0, 0.0, 0.0)
+
+
+def test_force_mass_sum_closed_form():
+    f = np.array([[3.0, 4.0, 0.0], [0.0, 0.0, 2.0], [1.0, 2.0, 2.0]])
+    m = np.array([5.0, 4.0, 0.5])
+    assert obs.force_mass_sum(f, m) == 1.0 + 0.5 + 6.0 == obs.force_mass_sum_exact(f, m)
+    assert prod.adaptive_timestep(0.3, 7.5) == (0.3 / 7.5) ** 0.5 and prod.adaptive_timestep(0.3, 0.0) is None
