@@ -554,7 +554,7 @@ int cavmd_set_wavevectors(cavmd_workspace* ws, size_t n_k, const double* h_wavev
     ws->rho_computed = false;
     ws->n_k = n_k;
     ws->n_chunks = (unsigned)((n_k + kWave - 1) / kWave);
-    ws->rho_blocks = (unsigned)(ws->num_cu * 4); // 4 blocks of 4 waves per CU: 16 of the 32 wave slots, all SIMDs busy
+    ws->rho_blocks = (unsigned)ws->num_cu; // one 1024-thread block (16 waves, 4 per SIMD) per CU: few partials to fold
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_kvec, sizeof(double) * 3 * n_k));
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho_part, sizeof(double) * 2 * kWave * (size_t)ws->n_chunks * ws->rho_blocks));
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho, sizeof(double) * 2 * n_k));
@@ -573,7 +573,7 @@ int cavmd_density_field(cavmd_workspace* ws, void* stream_, size_t N, const doub
         return CAVMD_ERR_CAPACITY;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    constexpr int kBlock = 256;
+    constexpr int kBlock = 1024;
     const size_t tiles = (N + kWave - 1) / kWave;
     size_t gb = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
     if (gb > ws->rho_blocks)
@@ -582,7 +582,7 @@ int cavmd_density_field(cavmd_workspace* ws, void* stream_, size_t N, const doub
         gb = 1;
     hipLaunchKernelGGL((density_partials_kernel<kBlock>), dim3((unsigned)gb, ws->n_chunks), dim3(kBlock), 0, stream,
                        reinterpret_cast<const char*>(d_position), position_stride, (unsigned)N, ws->d_kvec,
-                       (unsigned)ws->n_k, ws->d_rho_part);
+                       (unsigned)ws->n_k, make_sincos_coef(), ws->d_rho_part);
     CAVMD_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((density_fold_kernel<kBlock>), dim3(ws->n_chunks), dim3(kBlock), 0, stream, ws->d_rho_part,
                        (unsigned)gb, (unsigned)ws->n_k, ws->d_rho);

@@ -957,38 +957,61 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // with explicit FMAs (pi/2 = P1 + P2 to 107 bits; error ~1 ulp of r for |n| < 2^27), then the fdlibm kernel
 // polynomials on |r| <= pi/4 (S1..S6, C1..C6 of __kernel_sin / __kernel_cos, < 1 ulp each) and the quadrant swap.
 // ~27 fp64 operations against ~100 for the device library's sincos, whose Payne-Hanek path is kept for huge arguments.
-__device__ __forceinline__ void sincos_reduced(double x, double& s, double& c)
+// The constants arrive as a KERNEL ARGUMENT, i.e. in SGPRs: with literal constants hipcc materialises every
+// coefficient in a VGPR and emits v_mov_b64 + v_fmac_f64 pairs (18 extra moves per call); an SGPR addend can only be
+// the third operand of a three-address v_fma_f64.
+struct SinCosCoef
 {
-    const double n = __builtin_rint(x * 6.36619772367581382433e-01); // 2/pi
-    double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);     // P1 = double(pi/2)
-    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);            // P2 = pi/2 - P1
+    double inv_pio2, p1, p2;
+    double s1, s2, s3, s4, s5, s6;
+    double c1, c2, c3, c4, c5, c6;
+};
+inline SinCosCoef make_sincos_coef()
+{
+    SinCosCoef k;
+    k.inv_pio2 = 6.36619772367581382433e-01;
+    k.p1 = 1.57079632679489655800e+00; // double(pi/2)
+    k.p2 = 6.12323399573676603587e-17; // pi/2 - p1
+    k.s1 = -1.66666666666666324348e-01; k.s2 = 8.33333333332248946124e-03; k.s3 = -1.98412698298579493134e-04;
+    k.s4 = 2.75573137070700676789e-06;  k.s5 = -2.50507602534068634195e-08; k.s6 = 1.58969099521155010221e-10;
+    k.c1 = 4.16666666666666019037e-02;  k.c2 = -1.38888888888741095749e-03; k.c3 = 2.48015872894767294178e-05;
+    k.c4 = -2.75573143513906633035e-07; k.c5 = 2.08757232129817482790e-09;  k.c6 = -1.13596475577881948265e-11;
+    return k;
+}
+__device__ __forceinline__ void sincos_reduced(const SinCosCoef& k, double x, double& s, double& c)
+{
+    const double n = __builtin_rint(x * k.inv_pio2);
+    double r = __builtin_fma(-n, k.p1, x);
+    r = __builtin_fma(-n, k.p2, r);
     const double z = r * r;
     // sin(r) = r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(z, k.s6, k.s5);
+    ps = __builtin_fma(z, ps, k.s4);
+    ps = __builtin_fma(z, ps, k.s3);
+    ps = __builtin_fma(z, ps, k.s2);
+    ps = __builtin_fma(z, ps, k.s1);
     const double sr = __builtin_fma(z * r, ps, r);
     // cos(r) = 1 - (z/2 - z^2 (C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6))))))
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(z, k.c6, k.c5);
+    pc = __builtin_fma(z, pc, k.c4);
+    pc = __builtin_fma(z, pc, k.c3);
+    pc = __builtin_fma(z, pc, k.c2);
+    pc = __builtin_fma(z, pc, k.c1);
     const double cr = 1.0 - __builtin_fma(-z * z, pc, 0.5 * z);
     const int q = (int)n;
-    const double ss = (q & 1) ? cr : sr;
-    const double cc = (q & 1) ? sr : cr;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    // quadrant: odd q swaps sin and cos; the signs go straight into the sign bit of the high word
+    const bool swap = q & 1;
+    const double ss = swap ? cr : sr;
+    const double cc = swap ? sr : cr;
+    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cc) ^ (((q + 1) & 2) << 30), __double2loint(cc));
 }
 
 // part layout: [chunk][block][2][64] doubles
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __restrict__ pos, size_t pos_stride, unsigned N,
                                                                  const double* __restrict__ kvec, unsigned n_k,
-                                                                 double* __restrict__ part)
+                                                                 SinCosCoef coef, double* __restrict__ part)
 {
     constexpr int NW = BLOCK / kWave;
     __shared__ double s_acc[NW][2][kWave];
@@ -1025,7 +1048,7 @@ __global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __r
             if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
                 sincos(kr, &s, &c);
             else
-                sincos_reduced(kr, s, c);
+                sincos_reduced(coef, kr, s, c);
             re += c;
             im += s;
         }
@@ -1059,11 +1082,24 @@ __global__ __launch_bounds__(BLOCK) void density_fold_kernel(const double* __res
     const int wave = threadIdx.x / kWave;
     const unsigned chunk = blockIdx.x;
     double rh = 0.0, rl = 0.0, ih = 0.0, il = 0.0;
-    for (unsigned b = wave; b < nblocks; b += NW)
+    constexpr int BATCH = 8; // loads in flight per lane: without it every TwoSum waits for its own load
+    for (unsigned b0 = wave; b0 < nblocks; b0 += NW * BATCH)
     {
-        const double* p = part + ((size_t)chunk * nblocks + b) * 2 * kWave;
-        dd_acc(rh, rl, p[lane]);
-        dd_acc(ih, il, p[kWave + lane]);
+        double vr[BATCH], vi[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned b = b0 + j * NW;
+            const double* p = part + ((size_t)chunk * nblocks + (b < nblocks ? b : 0)) * 2 * kWave;
+            vr[j] = b < nblocks ? p[lane] : 0.0;
+            vi[j] = b < nblocks ? p[kWave + lane] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            dd_acc(rh, rl, vr[j]);
+            dd_acc(ih, il, vi[j]);
+        }
     }
     s_acc[wave][0][lane] = rh; s_acc[wave][1][lane] = rl;
     s_acc[wave][2][lane] = ih; s_acc[wave][3][lane] = il;
