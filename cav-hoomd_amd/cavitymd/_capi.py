@@ -68,7 +68,7 @@ _lock = threading.Lock()
 
 def build(force: bool = False) -> str:
     """Compile libcavmd.so for gfx950 with hipcc (cross-compiles without a GPU).  Idempotent."""
-    srcs = [os.path.join(CSRC_DIR, f) for f in ("cavmd_capi.hip", "cavmd_kernels.hpp")]
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".hpp")) and f != "microbench.hip"]
     srcs.append(os.path.normpath(os.path.join(CSRC_DIR, "..", "..", "include", "cavmd.h")))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

@@ -1,0 +1,307 @@
+// cavmd_observable_kernels.hpp -- kernels of the observables next to the force path:
+// density field rho(k), cavity-mode energies, sum |F_i| / m_i.  Overview: cavmd_kernels.hpp.
+#pragma once
+
+#include "cavmd_reduce.hpp"
+
+#pragma clang fp contract(off)
+
+// =====================================================================================================================
+// Observable next to the force path: density field rho(k) = sum_j exp(i k.r_j) over the WRAPPED
+// positions of all particles, for a set of wavevectors (reference: compute_density_field, src/cavitymd/analysis.py:34-47,
+// a Python loop over 50 wavevectors of numpy cos/sin over all particles).
+//
+// Mapping: LANE = WAVEVECTOR.  A wave loads 64 particles' positions with one coalesced round (lane = particle), then
+// walks them one by one: the particle's coordinates are broadcast with v_readlane (SGPR operands), every lane forms
+// k_lane . r = (x kx + y ky) + z kz and adds cos / sin to its own two accumulators.  The particle loop therefore has no
+// cross-lane traffic and no per-lane register pressure (2 accumulators), whatever the number of wavevectors; more than
+// 64 wavevectors are handled in chunks of 64 (blockIdx.y).  The kernel is bound by fp64 transcendental throughput
+// (~N * n_k sincos), not by memory: positions are 24 N bytes per chunk.
+// =====================================================================================================================
+namespace cavmd
+{
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sin and cos of one argument for |x| < 1e8: n = rint(x * 2/pi), r = x - n * pi/2 by a two-constant Cody-Waite step
+// with explicit FMAs (pi/2 = P1 + P2 to 107 bits; error ~1 ulp of r for |n| < 2^27), then the fdlibm kernel
+// polynomials on |r| <= pi/4 (S1..S6, C1..C6 of __kernel_sin / __kernel_cos, < 1 ulp each) and the quadrant swap.
+// ~27 fp64 operations against ~100 for the device library's sincos, whose Payne-Hanek path is kept for huge arguments.
+// The constants arrive as a KERNEL ARGUMENT, i.e. in SGPRs: with literal constants hipcc materialises every
+// coefficient in a VGPR and emits v_mov_b64 + v_fmac_f64 pairs (18 extra moves per call); an SGPR addend can only be
+// the third operand of a three-address v_fma_f64.
+struct SinCosCoef
+{
+    double inv_pio2, p1, p2;
+    double s1, s2, s3, s4, s5, s6;
+    double c1, c2, c3, c4, c5, c6;
+};
+inline SinCosCoef make_sincos_coef()
+{
+    SinCosCoef k;
+    k.inv_pio2 = 6.36619772367581382433e-01;
+    k.p1 = 1.57079632679489655800e+00; // double(pi/2)
+    k.p2 = 6.12323399573676603587e-17; // pi/2 - p1
+    k.s1 = -1.66666666666666324348e-01; k.s2 = 8.33333333332248946124e-03; k.s3 = -1.98412698298579493134e-04;
+    k.s4 = 2.75573137070700676789e-06;  k.s5 = -2.50507602534068634195e-08; k.s6 = 1.58969099521155010221e-10;
+    k.c1 = 4.16666666666666019037e-02;  k.c2 = -1.38888888888741095749e-03; k.c3 = 2.48015872894767294178e-05;
+    k.c4 = -2.75573143513906633035e-07; k.c5 = 2.08757232129817482790e-09;  k.c6 = -1.13596475577881948265e-11;
+    return k;
+}
+__device__ __forceinline__ void sincos_reduced(const SinCosCoef& k, double x, double& s, double& c)
+{
+    const double n = __builtin_rint(x * k.inv_pio2);
+    double r = __builtin_fma(-n, k.p1, x);
+    r = __builtin_fma(-n, k.p2, r);
+    const double z = r * r;
+    // sin(r) = r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
+    double ps = __builtin_fma(z, k.s6, k.s5);
+    ps = __builtin_fma(z, ps, k.s4);
+    ps = __builtin_fma(z, ps, k.s3);
+    ps = __builtin_fma(z, ps, k.s2);
+    ps = __builtin_fma(z, ps, k.s1);
+    const double sr = __builtin_fma(z * r, ps, r);
+    // cos(r) = 1 - (z/2 - z^2 (C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6))))))
+    double pc = __builtin_fma(z, k.c6, k.c5);
+    pc = __builtin_fma(z, pc, k.c4);
+    pc = __builtin_fma(z, pc, k.c3);
+    pc = __builtin_fma(z, pc, k.c2);
+    pc = __builtin_fma(z, pc, k.c1);
+    const double cr = 1.0 - __builtin_fma(-z * z, pc, 0.5 * z);
+    const int q = (int)n;
+    // quadrant: odd q swaps sin and cos; the signs go straight into the sign bit of the high word
+    const bool swap = q & 1;
+    const double ss = swap ? cr : sr;
+    const double cc = swap ? sr : cr;
+    s = __hiloint2double(__double2hiint(ss) ^ ((q & 2) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cc) ^ (((q + 1) & 2) << 30), __double2loint(cc));
+}
+
+// part layout: [chunk][block][2][64] doubles
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __restrict__ pos, size_t pos_stride, unsigned N,
+                                                                 const double* __restrict__ kvec, unsigned n_k,
+                                                                 SinCosCoef coef, double* __restrict__ part)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_acc[NW][2][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const unsigned chunk = blockIdx.y;
+    const unsigned k = chunk * kWave + lane;
+    const bool active = k < n_k;
+    const double kx = active ? kvec[3 * k + 0] : 0.0;
+    const double ky = active ? kvec[3 * k + 1] : 0.0;
+    const double kz = active ? kvec[3 * k + 2] : 0.0;
+
+    double re = 0.0, im = 0.0;
+    const unsigned ntiles = (N + kWave - 1) / kWave;
+    const unsigned gw = blockIdx.x * NW + wave, GW = gridDim.x * NW;
+    for (unsigned tile = gw; tile < ntiles; tile += GW)
+    {
+        const size_t i = (size_t)tile * kWave + lane;
+        double px = 0.0, py = 0.0, pz = 0.0;
+        if (i < N)
+        {
+            const double* p = reinterpret_cast<const double*>(pos + i * pos_stride);
+            px = p[0];
+            py = p[1];
+            pz = p[2];
+        }
+        const unsigned left = N - tile * kWave;
+        const int cnt = left < (unsigned)kWave ? (int)left : kWave; // wave-uniform
+        for (int j = 0; j < cnt; ++j)
+        {
+            const double x = readlane_f64(px, j), y = readlane_f64(py, j), z = readlane_f64(pz, j);
+            const double kr = (x * kx + y * ky) + z * kz;
+            double s, c;
+            if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
+                sincos(kr, &s, &c);
+            else
+                sincos_reduced(coef, kr, s, c);
+            re += c;
+            im += s;
+        }
+    }
+    s_acc[wave][0][lane] = re;
+    s_acc[wave][1][lane] = im;
+    __syncthreads();
+    if (wave == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+        {
+            re += s_acc[w][0][lane];
+            im += s_acc[w][1][lane];
+        }
+        double* out = part + ((size_t)chunk * gridDim.x + blockIdx.x) * 2 * kWave;
+        out[lane] = re;
+        out[kWave + lane] = im;
+    }
+}
+
+// one block per chunk of 64 wavevectors: thread (w, lane) folds blocks w, w+NW, ... of wavevector `lane` with TwoSum,
+// the NW waves meet in LDS.  out: interleaved (re, im) per wavevector.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void density_fold_kernel(const double* __restrict__ part, unsigned nblocks, unsigned n_k,
+                                                             double* __restrict__ out)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_acc[NW][4][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const unsigned chunk = blockIdx.x;
+    double rh = 0.0, rl = 0.0, ih = 0.0, il = 0.0;
+    constexpr int BATCH = 8; // loads in flight per lane: without it every TwoSum waits for its own load
+    for (unsigned b0 = wave; b0 < nblocks; b0 += NW * BATCH)
+    {
+        double vr[BATCH], vi[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned b = b0 + j * NW;
+            const double* p = part + ((size_t)chunk * nblocks + (b < nblocks ? b : 0)) * 2 * kWave;
+            vr[j] = b < nblocks ? p[lane] : 0.0;
+            vi[j] = b < nblocks ? p[kWave + lane] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            dd_acc(rh, rl, vr[j]);
+            dd_acc(ih, il, vi[j]);
+        }
+    }
+    s_acc[wave][0][lane] = rh; s_acc[wave][1][lane] = rl;
+    s_acc[wave][2][lane] = ih; s_acc[wave][3][lane] = il;
+    __syncthreads();
+    if (wave == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+        {
+            dd_merge(rh, rl, s_acc[w][0][lane], s_acc[w][1][lane]);
+            dd_merge(ih, il, s_acc[w][2][lane], s_acc[w][3][lane]);
+        }
+        const unsigned k = chunk * kWave + lane;
+        if (k < n_k)
+        {
+            out[2 * k] = rh + rl;
+            out[2 * k + 1] = ih + il;
+        }
+    }
+}
+
+// Cavity-mode kinetic energy (reference: CavityModeTracker.compute_cavity_properties, src/cavitymd/analysis.py:1324-1368):
+// KE = 1/2 m v.v of the photon found by the last force evaluation; HOOMD keeps the mass in vel.w.
+// out[0..3] = KE, harmonic PE (from the result block), KE + PE, temperature = (2/3) KE / k_B.
+__global__ void cavity_mode_kernel(const cavmd_result* __restrict__ res, const cavmd_double4* __restrict__ vel, double kB,
+                                   double* __restrict__ out)
+{
+    const int p = res->photon_idx;
+    double ke = 0.0, pe = 0.0, tot = 0.0, temp = 0.0;
+    if (p >= 0)
+    {
+        const cavmd_double4 v = vel[p];
+        ke = 0.5 * v.w * ((v.x * v.x + v.y * v.y) + v.z * v.z);
+        pe = res->energy[0];
+        tot = ke + pe;
+        temp = (2.0 / 3.0) * ke / kB;
+    }
+    out[0] = ke;
+    out[1] = pe;
+    out[2] = tot;
+    out[3] = temp;
+}
+} // namespace cavmd
+
+// =====================================================================================================================
+// Row f4 (data-parallel part): S = sum_i |F_i| / m_i over the net force, the quantity AdaptiveTimestepUpdater turns into
+// dt = sqrt(tol / S) (reference: src/cavitymd/simulation.py:66-92, via a host snapshot and a Python list comprehension).
+// One streaming pass over the Scalar4 net-force array and the Scalar4 velocity array (HOOMD keeps the mass in vel.w):
+// 64 B of lines per particle, 40 B algorithmic.  Same fixed-order compensated tree as the dipole.
+// =====================================================================================================================
+namespace cavmd
+{
+// six-step DPP wave tree + LDS fold for ONE double-double value; total in thread 0
+template <int BLOCK>
+__device__ __forceinline__ DD block_reduce_dd1(DD v)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_v[NW][2];
+    v = dd_sum(v, dd_dpp<0xB1>(v));
+    v = dd_sum(v, dd_dpp<0x4E>(v));
+    v = dd_sum(v, dd_dpp<0x124>(v));
+    v = dd_sum(v, dd_dpp<0x128>(v));
+    v = dd_sum(v, dd_shfl_xor(v, 16));
+    v = dd_sum(v, dd_shfl_xor(v, 32));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    if (lane == 0)
+    {
+        s_v[wave][0] = v.hi;
+        s_v[wave][1] = v.lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+            dd_merge(v.hi, v.lo, s_v[w][0], s_v[w][1]);
+    }
+    return v;
+}
+
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void force_mass_partials_kernel(const v2d* __restrict__ force2,
+                                                                    const v2d* __restrict__ vel2, unsigned N,
+                                                                    double* __restrict__ part /* [2][gridDim] */)
+{
+    constexpr unsigned TILE = BLOCK * UNROLL;
+    DD acc {0.0, 0.0};
+    const unsigned tiles = (N + TILE - 1) / TILE;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
+    {
+        const size_t base = (size_t)t * TILE + threadIdx.x;
+        v2d fxy[UNROLL], fzw[UNROLL], vzw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const size_t i = base + (size_t)u * BLOCK;
+            const bool ok = i < N;
+            const v2d zero = {0.0, 0.0}, one = {0.0, 1.0};
+            fxy[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i) : zero;
+            fzw[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i + 1) : zero;
+            vzw[u] = ok ? __builtin_nontemporal_load(vel2 + 2 * i + 1) : one;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const double n2 = (fxy[u].x * fxy[u].x + fxy[u].y * fxy[u].y) + fzw[u].x * fzw[u].x;
+            dd_acc(acc.hi, acc.lo, sqrt(n2) / vzw[u].y); // |F_i| / m_i; padding lanes add 0 / 1
+        }
+    }
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+    {
+        part[blockIdx.x] = acc.hi;
+        part[gridDim.x + blockIdx.x] = acc.lo;
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void force_mass_fold_kernel(const double* __restrict__ part, unsigned nparts,
+                                                                double* __restrict__ out)
+{
+    DD acc {0.0, 0.0};
+    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
+        dd_merge(acc.hi, acc.lo, part[p], part[nparts + p]);
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+        out[0] = acc.hi + acc.lo;
+}
+} // namespace cavmd
