@@ -31,7 +31,8 @@ def short(name):
 
 def collect(directory, counter):
     acc = defaultdict(list)
-    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+    paths = sorted(glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for path in paths[-1:]:  # the most recent run only (gpurun_out/ accumulates earlier ones)
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
