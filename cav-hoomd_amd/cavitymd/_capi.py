@@ -73,6 +73,8 @@ def build(force: bool = False) -> str:
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", CSRC_DIR, "-s", "libcavmd.so"] + (["-B"] if force else []), check=True)
+    # the pybind11 flavour of the shim (cavitymd._cavitymd); make rebuilds it only when stale
+    subprocess.run(["make", "-C", CSRC_DIR, "-s", "pymod"], check=True)
     return LIB_PATH
 
 
