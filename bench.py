@@ -184,6 +184,25 @@ def side_measurement(cfg, device, frames, steps, warmup):
     return out
 
 
+def energy_poll_measurement(cfg, device, frames, steps, warmup):
+    """Variant (ii) of SURVEY.md 8(d): every evaluation is followed by the three energy getters, as the reference's
+    EnergyTracker does at period 1.  (The getters spin on a host-visible flag the publishing block sets; no memcpy.)"""
+    ring = build_ring(cfg, frames, device)
+    nf = len(ring)
+    for s in range(warmup):
+        ring[s % nf].compute.compute(s)
+        ring[s % nf].compute.getEnergies()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        c = ring[s % nf].compute
+        c.compute(s)
+        c.getEnergies()
+    t = time.perf_counter() - t0
+    return {"N": ring[0].n, "frames": nf, "evals_per_s": steps / t, "us_per_eval": 1e6 * t / steps,
+            "note": "evaluation + energy getters every step (host-visible result block, no memcpy, no stream sync)"}
+
+
 def density_field_measurement(cfg, device, n_k=50, kmag=1.0, steps=20, warmup=3):
     """Row f3 side measurement: rho(k) for 50 Fibonacci-sphere wavevectors (the reference tracker's default)."""
     from cavitymd import observables
@@ -268,6 +287,8 @@ def main():
             extras["1e5_ring"] = side_measurement(synthetic.config2(), ctx.device, 64, 300, 30)
             extras["1e7_hbm"] = side_measurement(synthetic.config4(), ctx.device, 2, 50, 5)
             extras["density_field_1e6_50k"] = density_field_measurement(cfg, ctx.device)
+            extras["1e6_energy_poll_every_step"] = energy_poll_measurement(cfg, ctx.device, spec["frames"], spec["steps"],
+                                                                           spec["warmup"])
             line["extras"] = extras
     if ctx.rank == 0:
         print(json.dumps(line), flush=True)

@@ -48,7 +48,8 @@ struct cavmd_workspace
     double* d_part = nullptr;
     int* d_ipart = nullptr;
     cavmd_result* d_result = nullptr;
-    cavmd_result* h_result = nullptr; // pinned
+    HostResult* h_result = nullptr;     // pinned + mapped: the publishing block writes the result + ready flag here
+    HostResult* h_result_dev = nullptr; // device-side address of h_result
     hipStream_t last_stream = nullptr;
     bool computed = false;
     uint64_t sequence = 0;
@@ -259,13 +260,15 @@ int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
     if (e == hipSuccess)
         e = hipMemset(ws->d_result, 0, sizeof(cavmd_result));
     if (e == hipSuccess)
-        e = hipHostMalloc((void**)&ws->h_result, sizeof(cavmd_result), hipHostMallocDefault);
+        e = hipHostMalloc((void**)&ws->h_result, sizeof(HostResult), hipHostMallocMapped);
+    if (e == hipSuccess)
+        e = hipHostGetDevicePointer((void**)&ws->h_result_dev, ws->h_result, 0);
     if (e != hipSuccess)
     {
         cavmd_destroy(ws);
         return (int)e;
     }
-    memset(ws->h_result, 0, sizeof(cavmd_result));
+    memset(ws->h_result, 0, sizeof(HostResult));
     *out_ws = ws;
     return CAVMD_OK;
 }
@@ -383,16 +386,16 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
         if (ws->map_nt_store)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2);
         else
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2);
     }
     else
     {
         // ---- three-launch variant (kept for A/B): finalize, then a force map that reads the result block
         st = ls.launch(1, finalize_kernel<AosInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
-                       part, ws->sequence, ws->d_result);
+                       part, ws->sequence, ws->d_result, ws->h_result_dev);
         if (st != CAVMD_OK)
             return st;
         const cavmd_result* res = ws->d_result;
@@ -479,7 +482,7 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
         return st;
     ws->sequence += 1;
     st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
-                   part, ws->sequence, ws->d_result);
+                   part, ws->sequence, ws->d_result, ws->h_result_dev);
     if (st != CAVMD_OK)
         return st;
     const unsigned g2 = grid_for(N, kMapBlock, ws->num_cu, 8);
@@ -503,9 +506,25 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
     if (!ws->computed)
         return CAVMD_ERR_NOT_COMPUTED;
     DeviceGuard guard(ws->device);
-    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_result, ws->d_result, sizeof(cavmd_result), hipMemcpyDeviceToHost, ws->last_stream));
-    CAVMD_HIP_TRY(hipStreamSynchronize(ws->last_stream));
-    memcpy(out, ws->h_result, sizeof(cavmd_result));
+    // The publishing block stores the result block and then a sequence flag (system-scope release) into mapped pinned
+    // host memory.  Spin on that flag: the energies arrive as soon as the prologue of the force map has them, about a
+    // PCIe write after, instead of a stream synchronisation (~15 us).  The stream going idle ends the wait as well
+    // (a graph replay carries a frozen sequence number, and a failed launch never sets the flag).
+    const uint64_t want = ws->sequence;
+    for (;;)
+    {
+        if (__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE) == want)
+            break;
+        const hipError_t q = hipStreamQuery(ws->last_stream);
+        if (q == hipSuccess)
+        {
+            (void)__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE);
+            break;
+        }
+        if (q != hipErrorNotReady)
+            return (int)q;
+    }
+    memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
     return CAVMD_OK;
 }
 

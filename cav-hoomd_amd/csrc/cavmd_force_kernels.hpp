@@ -379,15 +379,33 @@ __device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, con
     res->reserved = 0.0;
 }
 
+// Host hand-off of the result block: `host` points at mapped pinned host memory.  The block is written first, then the
+// evaluation's sequence number is release-stored at SYSTEM scope into host->ready, so a host thread that acquires
+// ready == sequence sees the whole block (cavmd_result_read spins on it instead of paying a stream synchronisation).
+struct HostResult
+{
+    cavmd_result result;
+    uint64_t ready;
+};
+__device__ __forceinline__ void publish_to_host(HostResult* __restrict__ host, const Scalars& sc, unsigned N,
+                                                unsigned nparts, uint64_t sequence)
+{
+    write_result(&host->result, sc, N, nparts, sequence);
+    __hip_atomic_store(&host->ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- kernel 2 (three-launch path): one block publishes the result block ---------------------------------------
 template <class Input, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void finalize_kernel(Input in, unsigned N, unsigned nparts, double Lx, double Ly,
                                                          double Lz, DeviceParams prm, Partials part, uint64_t sequence,
-                                                         cavmd_result* __restrict__ res)
+                                                         cavmd_result* __restrict__ res, HostResult* __restrict__ res_host)
 {
     const Scalars sc = reduce_partials_and_finalize<Input, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part, true);
     if (threadIdx.x == 0)
+    {
         write_result(res, sc, N, nparts, sequence);
+        publish_to_host(res_host, sc, N, nparts, sequence);
+    }
 }
 
 // ---- force map, HOOMD AoS force array written as dense 16-byte chunks ------------------------------------------
@@ -521,6 +539,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
                                                                     double Ly, double Lz, DeviceParams prm, int L_typeid,
                                                                     Partials part, uint64_t sequence,
                                                                     cavmd_result* __restrict__ res,
+                                                                    HostResult* __restrict__ res_host,
                                                                     v2d* __restrict__ force2)
 {
     __shared__ double s_m[5];
@@ -545,7 +564,10 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
         s_mi[0] = sc.photon;
         s_mi[1] = sc.nL;
         if (blockIdx.x == 0)
+        {
             write_result(res, sc, N, nparts, sequence);
+            publish_to_host(res_host, sc, N, nparts, sequence);
+        }
     }
     __syncthreads();
     MapScalars m;

@@ -185,11 +185,12 @@ int main(int argc, char** argv)
         CHECK(hipMemcpy(d_img[f], h_img.data(), N * 12, hipMemcpyHostToDevice));
     }
     const unsigned max_parts = CU * 16;
-    double* d_part; int* d_ipart; cavmd_result* d_res; double* d_sink;
+    double* d_part; int* d_ipart; cavmd_result* d_res; double* d_sink; HostResult* d_hres;
     CHECK(hipMalloc((void**)&d_part, sizeof(double) * kNumPartDoubles * max_parts));
     CHECK(hipMalloc((void**)&d_ipart, sizeof(int) * kNumPartInts * max_parts));
     CHECK(hipMalloc((void**)&d_res, sizeof(cavmd_result)));
     CHECK(hipMalloc((void**)&d_sink, 64));
+    CHECK(hipMalloc((void**)&d_hres, sizeof(HostResult)));
     CHECK(hipMemset(d_part, 0, sizeof(double) * kNumPartDoubles * max_parts));
     CHECK(hipMemset(d_ipart, 0, sizeof(int) * kNumPartInts * max_parts));
     Partials part {d_part, d_ipart, max_parts};
@@ -256,10 +257,10 @@ int main(int argc, char** argv)
                      hipLaunchKernelGGL((flat_write_kernel<256, 4, true>), dim3(grid(2 * N, 1024, 8)), dim3(256), 0, st, (v2d*)d_frc[f], 2 * N); }, {}});
     V.push_back({"finalize (2048 partials)", 0.0, [&](int f) {
                      DeviceParams p; p.g = 1e-3; p.K = 0.0091 * 0.0091; p.gK = p.g / p.K; p.g2K = p.g * p.g / p.K;
-                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 2048u, L, L, L, p, part, 1ull, d_res); }, {}});
+                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 2048u, L, L, L, p, part, 1ull, d_res, d_hres); }, {}});
     V.push_back({"finalize (512 partials)", 0.0, [&](int f) {
                      DeviceParams p; p.g = 1e-3; p.K = 0.0091 * 0.0091; p.gK = p.g / p.K; p.g2K = p.g * p.g / p.K;
-                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 512u, L, L, L, p, part, 1ull, d_res); }, {}});
+                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, 512u, L, L, L, p, part, 1ull, d_res, d_hres); }, {}});
 
 
     // ---- whole evaluations: reduce -> finalize -> map on the same frame, as cavmd_compute_hoomd enqueues them ----
@@ -274,7 +275,7 @@ int main(int argc, char** argv)
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_nt1_of(f), n, L, L, L, 2, part); \
                      else                                                                                               \
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInput, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_of(f), n, L, L, L, 2, part); \
-                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, g1, L, L, L, P, part, 1ull, d_res); \
+                     hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(f), n, g1, L, L, L, P, part, 1ull, d_res, d_hres); \
                      hipLaunchKernelGGL((force_map_aos_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, d_chg[f], (const v2d*)d_pos[f], n, 1e-3, 2, d_res, (v2d*)d_frc[f]); \
                  }, {}})
 #define SEQ2(NAME, KB, KU, KP, KNT, KBPC, MB, MU, MNT, MBPC)                                                                \
@@ -286,7 +287,7 @@ int main(int argc, char** argv)
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_nt1_of(f), n, L, L, L, 2, part); \
                      else                                                                                               \
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInput, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_of(f), n, L, L, L, 2, part); \
-                     hipLaunchKernelGGL((force_map_aos_fused_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, in_of(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, (v2d*)d_frc[f]); \
+                     hipLaunchKernelGGL((force_map_aos_fused_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, in_of(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f]); \
                  }, {}})
     SEQ3("SEQ3 K1 simple nt1 bpc1 | fin | K2 u4 bpc8", 256, 4, false, 1, 1, 256, 4, false, 8);
     SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc2", 256, 4, false, 1, 1, 256, 4, false, 2);
@@ -335,7 +336,7 @@ int main(int argc, char** argv)
         unsigned long long best[5] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
         for (int rep = 0; rep < 20; ++rep)
         {
-            hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(rep % frames), n, np, L, L, L, P, part, 1ull, d_res);
+            hipLaunchKernelGGL((finalize_kernel<AosInput, 256>), dim3(1), dim3(256), 0, st, in_of(rep % frames), n, np, L, L, L, P, part, 1ull, d_res, d_hres);
             CHECK(hipDeviceSynchronize());
             unsigned long long h[16];
             CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof(h)));
