@@ -111,12 +111,25 @@ def kernel_times(ring, steps, warmup):
     run_steps(ring, steps, first=warmup)
     tot = [0.0, 0.0, 0.0]
     launches = 0
+    samples = []
     for f in ring:
+        samples.append(f.compute.workspace.profile_samples())
         ms, n = f.compute.workspace.profile_read()
         tot = [a + b for a, b in zip(tot, ms)]
         launches += n
         f.compute.workspace.profile_enable(False)
+    kernel_times.last_samples = np.concatenate(samples, axis=0) if samples else np.zeros((0, 3))
     return [t / max(launches, 1) for t in tot], launches
+
+
+def percentiles(samples_ms):
+    """median and p10/p90 (microseconds) of the per-evaluation kernel times, per kernel and for their sum."""
+    if len(samples_ms) == 0:
+        return None
+    us = 1e3 * np.asarray(samples_ms)
+    cols = {"reduce": us[:, 0], "map": us[:, 2], "evaluation_kernels": us.sum(axis=1)}
+    return {k: {"p10": float(np.percentile(v, 10)), "median": float(np.percentile(v, 50)),
+                "p90": float(np.percentile(v, 90))} for k, v in cols.items()}
 
 
 def roofline_block(n, kt_ms):
@@ -255,6 +268,7 @@ def main():
 
     kt, launches = kernel_times(ring, spec["steps"], spec["warmup"])
     roof = roofline_block(n, kt)
+    roof["kernel_time_us_percentiles"] = percentiles(kernel_times.last_samples)
     pmc = load_pmc_traffic(n)
     if pmc is not None:
         roof["traffic"] = pmc.get(roof["kernel"], {}).get("hbm_bytes_per_launch")

@@ -58,7 +58,7 @@ class Result(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "cavmd_make_params", "cavmd_create", "cavmd_destroy", "cavmd_compute_hoomd", "cavmd_compute_soa",
     "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_set_wavevectors", "cavmd_density_field",
-    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_profile_enable", "cavmd_profile_read",
+    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_profile_enable", "cavmd_profile_read", "cavmd_profile_samples",
     "cavmd_set_tunable", "cavmd_get_tunable", "cavmd_device_info", "cavmd_error_string", "cavmd_version",
 )
 
@@ -122,6 +122,8 @@ def load():
         lib.cavmd_profile_enable.restype = ci
         lib.cavmd_profile_read.argtypes = [vp, P(dbl * 3), P(ctypes.c_uint64)]
         lib.cavmd_profile_read.restype = ci
+        lib.cavmd_profile_samples.argtypes = [vp, vp, sz, P(sz)]
+        lib.cavmd_profile_samples.restype = ci
         lib.cavmd_set_tunable.argtypes = [vp, ctypes.c_char_p, ci]
         lib.cavmd_set_tunable.restype = ci
         lib.cavmd_get_tunable.argtypes = [vp, ctypes.c_char_p, P(ci)]
@@ -250,6 +252,15 @@ class Workspace:
         n = ctypes.c_uint64()
         check(self._lib.cavmd_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)), "cavmd_profile_read")
         return [float(ms[0]), float(ms[1]), float(ms[2])], int(n.value)
+
+    def profile_samples(self, cap: int = 4096):
+        """(n, 3) array of per-evaluation kernel times in ms {reduce, finalize, map}; call before profile_read()."""
+        import numpy as np
+        out = np.empty((cap, 3), dtype=np.float64)
+        n = ctypes.c_size_t()
+        check(self._lib.cavmd_profile_samples(self._h, ctypes.c_void_p(out.ctypes.data), int(cap), ctypes.byref(n)),
+              "cavmd_profile_samples")
+        return out[:n.value].copy()
 
     def set_tunable(self, name: str, value: int) -> None:
         check(self._lib.cavmd_set_tunable(self._h, name.encode(), int(value)), f"cavmd_set_tunable({name})")

@@ -4,7 +4,8 @@
 // (src/CavityForceComputeGPU.cc:102-253) and kernel::gpu_compute_cavity_force
 // (src/CavityForceComputeGPU.cu:507-617).  Where the reference does 4 memsets, 1 H2D and 2 blocking
 // D2H copies, a device synchronise and a host scan of the position array per step, this enqueues
-// three kernels on the caller's stream and returns; energies are fetched lazily by cavmd_energies.
+// two kernels on the caller's stream and returns; the energies reach the host through a block of mapped pinned
+// memory that cavmd_energies polls (no copy, no stream synchronisation).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -30,6 +31,7 @@ constexpr int kMapUnroll = 4;
 constexpr int kMaxBlocksPerCU = 16;
 constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
+constexpr size_t kMaxSamples = 4096;
 constexpr size_t kChargeTemporalMaxN = (size_t)1 << 21; // 16 MiB of charges
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
@@ -67,6 +69,7 @@ struct cavmd_workspace
     std::vector<unsigned> slot_mask; // which of the three kernels a slot's evaluation launched
     double acc_ms[3] = {0, 0, 0};
     uint64_t acc_launches = 0;
+    std::vector<float> samples; // 3 per evaluation, capped at kMaxSamples evaluations
     // observables (rows f2 / f3)
     size_t n_k = 0;
     unsigned n_chunks = 0;
@@ -137,6 +140,7 @@ int drain_profile(cavmd_workspace* ws)
     {
         hipEvent_t* ev = &ws->events[kEventsPerSlot * s];
         const unsigned used = ws->slot_mask[s];
+        float sample[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < 3; ++k)
         {
             if (!(used & (1u << k)))
@@ -145,8 +149,12 @@ int drain_profile(cavmd_workspace* ws)
             float ms = 0.f;
             CAVMD_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
             ws->acc_ms[k] += (double)ms;
+            sample[k] = ms;
         }
         ws->acc_launches += 1;
+        if (ws->samples.size() >= 3 * kMaxSamples)
+            ws->samples.erase(ws->samples.begin(), ws->samples.begin() + 3);
+        ws->samples.insert(ws->samples.end(), sample, sample + 3);
     }
     ws->pending = 0;
     return CAVMD_OK;
@@ -727,6 +735,24 @@ int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* launches)
     }
     *launches = ws->acc_launches;
     ws->acc_launches = 0;
+    ws->samples.clear();
+    return CAVMD_OK;
+}
+
+int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap, size_t* n)
+{
+    if (!ws || !out || !n)
+        return CAVMD_ERR_INVALID_VALUE;
+    DeviceGuard guard(ws->device);
+    int st = drain_profile(ws);
+    if (st != CAVMD_OK)
+        return st;
+    const size_t have = ws->samples.size() / 3;
+    const size_t take = have < cap ? have : cap;
+    const size_t first = have - take;
+    for (size_t i = 0; i < 3 * take; ++i)
+        out[i] = (double)ws->samples[3 * first + i];
+    *n = take;
     return CAVMD_OK;
 }
 

@@ -218,6 +218,11 @@ CAVMD_API int cavmd_profile_enable(cavmd_workspace* ws, int on);
  * *launches = evaluations accumulated.  Resets the accumulators. */
 CAVMD_API int cavmd_profile_read(cavmd_workspace* ws, double ms[3], uint64_t* launches);
 
+/* Per-evaluation samples behind cavmd_profile_read: copies up to `cap` triples {reduce, finalize, map} in
+ * milliseconds (oldest first) into out[3 * cap] and stores the count in *n.  Call BEFORE cavmd_profile_read, which
+ * clears them.  At most the last 4096 evaluations are kept. */
+CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap, size_t* n);
+
 /* ---- tuning / introspection ------------------------------------------------------------------- */
 /* Launch knobs (for A/B measurements; the defaults are the measured best on MI355X).  name is one of
  *   "reduce_blocks_per_cu" 1..16   grid of the reduction = min(tiles, CUs * value); also the number of partials
