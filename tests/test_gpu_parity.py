@@ -221,6 +221,52 @@ def test_full_size_parity_and_properties(ref, oracle_mod, maker, kwargs):
     assert d_shift[1] == gpu["dipole"][1] and d_shift[2] == gpu["dipole"][2]
 
 
+def test_150_million_particles_64bit_offsets():
+    """N = 150 000 001: the pos and force arrays are 4.8 GB each, so every byte offset beyond 2^32 is exercised.
+    Inputs are generated on the device; the check uses device-side fp64 reductions (torch) for the dipole and an
+    exact element-wise recomputation of the force map from the kernel's own Dq."""
+    n = 150_000_001
+    dev = "cuda"
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    L = (531.0, 531.0, 531.0)
+    pos = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    pos[:, :3] = (torch.rand((n, 3), dtype=torch.float64, device=dev, generator=gen) - 0.5) * L[0]
+    tags = torch.zeros(n, dtype=torch.int64, device=dev)
+    tags[1::2] = 1
+    tags[-1] = 2                                              # photon last, as the driver appends it
+    pos[:, 3] = tags.view(torch.float64)
+    del tags
+    charge = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    charge -= charge[:-1].mean()
+    charge[-1] = 0.0
+    image = torch.randint(-2, 3, (n, 3), dtype=torch.int32, device=dev, generator=gen)
+    force = torch.full((n, 4), float("nan"), dtype=torch.float64, device=dev)
+    ws = _capi.Workspace(n)
+    prm = _capi.make_params(2000.0 / 219474.63, 1e-3, 1.0)
+    ws.compute_hoomd(0, n, pos.data_ptr(), charge.data_ptr(), image.data_ptr(), L, 2, prm, force.data_ptr())
+    torch.cuda.synchronize()
+    res = ws.result()
+    assert res.photon_idx == n - 1 and res.n_photon_typed == 1 and res.n_particles == n
+    # dipole: torch's tree sum is accurate to ~log2(N) eps relative to sum|t|; ours is compensated
+    d = np.array(res.dipole[:])
+    Lt = torch.tensor(L, device=dev)
+    for k in range(3):
+        t = charge[:-1] * (pos[:-1, k] + image[:-1, k].to(torch.float64) * Lt[k])
+        want, scale = float(t.sum()), float(t.abs().sum())
+        assert abs(d[k] - want) <= 64 * EPS * scale, (k, d[k], want)
+        del t
+    # force map, exactly: F = ((-g) c) Dq with the kernel's own Dq; z and w zero; photon row = F_L
+    g = prm.couplstr
+    s = (-g) * charge
+    for k in range(2):
+        assert torch.equal(force[:-1, k], s[:-1] * res.Dq[k])
+    assert not force[:-1, 2:].any() and not torch.isnan(force).any()
+    assert force[-1].tolist() == [res.photon_force[0], res.photon_force[1], res.photon_force[2], 0.0]
+    # the tail of the arrays (offsets > 4 GiB) really was reached
+    assert (n - 1) * 32 > 2**32 and float(force[-2, 0]) == float(s[-2] * res.Dq[0])
+
+
 # ---- edge cases -------------------------------------------------------------------------------------------------------------
 def _random_cfg(n, seed, photon_at=None, L=(31.0, 17.5, 23.25), image_range=3, photon_charge=0.0):
     rng = np.random.default_rng(seed)
