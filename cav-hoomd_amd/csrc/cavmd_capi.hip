@@ -32,7 +32,7 @@ constexpr int kMaxBlocksPerCU = 16;
 constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
 constexpr size_t kMaxSamples = 4096;
-constexpr size_t kChargeTemporalMaxN = (size_t)1 << 21; // 16 MiB of charges
+constexpr size_t kChargeTemporalMaxN = 5000000; // measured crossover: temporal charge loads win up to 4e6, tie at 6e6, lose at 1e7
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
 static_assert(sizeof(cavmd_int3) == 12, "int3 layout");
@@ -356,7 +356,8 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
     // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
     // by the force map: keeping it temporal lets the map hit it in the Infinity Cache while 8 N bytes are small
-    // (measured -4 % per evaluation at N = 1e6) but costs +16 % at N = 1e7, where it only evicts useful lines.
+    // (measured -4 % per evaluation at N = 1e6, -3 % at 4e6, 0 at 6e6) but costs +16 % at N = 1e7, where it only
+    // evicts useful lines.
     int nt = ws->reduce_nt_load;
     if (nt < 0)
         nt = (N <= kChargeTemporalMaxN) ? 1 : 2;
