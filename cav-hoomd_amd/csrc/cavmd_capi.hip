@@ -32,6 +32,7 @@ constexpr int kMaxBlocksPerCU = 16;
 constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
 constexpr size_t kMaxSamples = 4096;
+constexpr size_t kNtStoreMinN = 200000;       // force stores: neutral at 1e5, -3.6 % at 3e5, -4.3 % at 1e6, -5.8 % at 1e7
 constexpr size_t kChargeTemporalMaxN = 5000000; // measured crossover: temporal charge loads win up to 4e6, tie at 6e6, lose at 1e7
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
@@ -59,7 +60,7 @@ struct cavmd_workspace
     // Defaults from interleaved A/B runs on MI355X (csrc/microbench.hip; profiles/r01/microbench_*.txt):
     int reduce_blocks_per_cu = 1; // <= 256 partials: the fused force map folds them with one load per thread
     int map_blocks_per_cu = 2;    // every fused block re-folds the partials, so few, long-lived blocks
-    int map_nt_store = 0;
+    int map_nt_store = -1;        // -1 auto (non-temporal from kNtStoreMinN particles up), 0 plain, 1 non-temporal
     int reduce_nt_load = -1;      // -1 auto, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     // profiling
@@ -390,10 +391,14 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     ws->sequence += 1;
     const unsigned g2 = grid_for(2 * N, kMapBlock * kMapUnroll, ws->num_cu, ws->map_blocks_per_cu);
     v2d* force2 = reinterpret_cast<v2d*>(d_force);
+    // Force stores bypass the caches for all but small N: the array is consumed much later (by the integrator, after
+    // every other force of the step), and not leaving 32 N dirty bytes behind shortens this kernel's drain and spares
+    // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
+    const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
     if (ws->fused_finalize)
     {
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
-        if (ws->map_nt_store)
+        if (nt_store)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
                            Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2);
         else
@@ -409,7 +414,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
             return st;
         const cavmd_result* res = ws->d_result;
         const double g = params->couplstr;
-        if (ws->map_nt_store)
+        if (nt_store)
             st = ls.launch(2, force_map_aos_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, d_charge, in.pos2, n, g,
                            L_typeid, res, force2);
         else
@@ -777,7 +782,7 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
     }
     if (!strcmp(name, "map_nt_store"))
     {
-        if (value != 0 && value != 1)
+        if (value < -1 || value > 1)
             return CAVMD_ERR_INVALID_VALUE;
         ws->map_nt_store = value;
         return CAVMD_OK;

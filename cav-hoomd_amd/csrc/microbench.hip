@@ -292,6 +292,12 @@ int main(int argc, char** argv)
     SEQ3("SEQ3 K1 simple nt1 bpc1 | fin | K2 u4 bpc8", 256, 4, false, 1, 1, 256, 4, false, 8);
     SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc2", 256, 4, false, 1, 1, 256, 4, false, 2);
     SEQ2("SEQ2 K1 simple nt2 bpc1 | fused u4 bpc2", 256, 4, false, 2, 1, 256, 4, false, 2);
+    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc2 ntstore", 256, 4, false, 1, 1, 256, 4, true, 2);
+    SEQ2("SEQ2 K1 simple nt2 bpc1 | fused u4 bpc2 ntstore", 256, 4, false, 2, 1, 256, 4, true, 2);
+    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc3", 256, 4, false, 1, 1, 256, 4, false, 3);
+    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u2 bpc2", 256, 4, false, 1, 1, 256, 2, false, 2);
+    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u8 bpc2", 256, 4, false, 1, 1, 256, 8, false, 2);
+    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u8 bpc1", 256, 4, false, 1, 1, 256, 8, false, 1);
     SEQ2("SEQ2 K1 simple nt1 bpc2 | fused u4 bpc2", 256, 4, false, 1, 2, 256, 4, false, 2);
     SEQ2("SEQ2 K1 simple nt1 bpc4 | fused u4 bpc2", 256, 4, false, 1, 4, 256, 4, false, 2);
     SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u4 bpc2", 256, 4, true, 1, 1, 256, 4, false, 2);

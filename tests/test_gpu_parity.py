@@ -349,7 +349,7 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     refout = ref_eval(ref, oracle_mod, cfg)
     check_parity(cfg, base, refout)
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
-                {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
+                {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"map_nt_store": 0}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
                 {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
