@@ -24,7 +24,7 @@ using namespace cavmd;
 namespace
 {
 constexpr int kReduceBlock = 256;
-constexpr int kReduceUnroll = 4;
+constexpr int kReduceUnroll = 2; // particles per lane and tile; 2 beats 4 by 6 % at 1e6 and 11 % at 3e5, ties at 1e7
 constexpr int kFinalizeBlock = 256;
 constexpr int kMapBlock = 256;
 constexpr int kMapUnroll = 4;
@@ -349,10 +349,10 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     int st;
 
     // ---- launch 1: per-block partial sums + photon search
-    // Tile depth: 4 particles per lane (1024 per block) when that still gives every CU a block; shallower tiles for
-    // small N so that all 256 CUs take part (at N = 1e5 a 1024-particle tile would occupy 98 CUs).
+    // Tile depth: 2 particles per lane (512 per block; 8 loads in flight per lane); 1 for very small N so that a
+    // useful share of the CUs takes part (measured: 2 still wins at N = 1e5, where it fills 195 CUs).
     int unroll = kReduceUnroll;
-    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu)
+    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu / 4)
         unroll >>= 1;
     const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
     // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
@@ -377,9 +377,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         else                                                                                                          \
             CAVMD_LAUNCH_REDUCE(2, UNR)                                                                               \
     }
-    if (unroll == 4)
-        CAVMD_LAUNCH_REDUCE_NT(4)
-    else if (unroll == 2)
+    if (unroll == 2)
         CAVMD_LAUNCH_REDUCE_NT(2)
     else
         CAVMD_LAUNCH_REDUCE_NT(1)

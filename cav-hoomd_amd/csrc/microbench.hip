@@ -289,29 +289,22 @@ int main(int argc, char** argv)
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInput, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_of(f), n, L, L, L, 2, part); \
                      hipLaunchKernelGGL((force_map_aos_fused_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, in_of(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f]); \
                  }, {}})
-    SEQ3("SEQ3 K1 simple nt1 bpc1 | fin | K2 u4 bpc8", 256, 4, false, 1, 1, 256, 4, false, 8);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc2", 256, 4, false, 1, 1, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 simple nt2 bpc1 | fused u4 bpc2", 256, 4, false, 2, 1, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc2 ntstore", 256, 4, false, 1, 1, 256, 4, true, 2);
-    SEQ2("SEQ2 K1 simple nt2 bpc1 | fused u4 bpc2 ntstore", 256, 4, false, 2, 1, 256, 4, true, 2);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u4 bpc3", 256, 4, false, 1, 1, 256, 4, false, 3);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u2 bpc2", 256, 4, false, 1, 1, 256, 2, false, 2);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u8 bpc2", 256, 4, false, 1, 1, 256, 8, false, 2);
-    SEQ2("SEQ2 K1 simple nt1 bpc1 | fused u8 bpc1", 256, 4, false, 1, 1, 256, 8, false, 1);
-    SEQ2("SEQ2 K1 simple nt1 bpc2 | fused u4 bpc2", 256, 4, false, 1, 2, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 simple nt1 bpc4 | fused u4 bpc2", 256, 4, false, 1, 4, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u4 bpc2", 256, 4, true, 1, 1, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt2 bpc1 | fused u4 bpc2", 256, 4, true, 2, 1, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc2 | fused u4 bpc2", 256, 4, true, 1, 2, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt2 bpc2 | fused u4 bpc2", 256, 4, true, 2, 2, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u4 bpc1", 256, 4, true, 1, 1, 256, 4, false, 1);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u4 bpc3", 256, 4, true, 1, 1, 256, 4, false, 3);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u4 bpc4", 256, 4, true, 1, 1, 256, 4, false, 4);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused u2 bpc4", 256, 4, true, 1, 1, 256, 2, false, 4);
-    SEQ2("SEQ2 K1 dbuf nt1 bpc1 | fused b512 u4 bpc1", 256, 4, true, 1, 1, 512, 4, false, 1);
-    SEQ2("SEQ2 K1 dbuf u2 nt1 bpc2 | fused u4 bpc2", 256, 2, true, 1, 2, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf u2 nt1 bpc4 | fused u4 bpc2", 256, 2, true, 1, 4, 256, 4, false, 2);
-    SEQ2("SEQ2 K1 dbuf nt2 bpc1 | fused u8 bpc2", 256, 4, true, 2, 1, 256, 8, false, 2);
+    // NT = charge-load policy of the reduction (1 below 5e6 particles, 2 above), stores non-temporal
+#define SWEEP(NT)                                                                                                   \
+    SEQ2("SEQ2 prev: K1 u4 bpc1 | fused u4 bpc2 nts", 256, 4, false, NT, 1, 256, 4, true, 2);                       \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused u4 bpc2 nts", 256, 2, false, NT, 1, 256, 4, true, 2);                             \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused u8 bpc2 nts", 256, 2, false, NT, 1, 256, 8, true, 2);                             \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused u8 bpc3 nts", 256, 2, false, NT, 1, 256, 8, true, 3);                             \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused u8 bpc1 nts", 256, 2, false, NT, 1, 256, 8, true, 1);                             \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused u4 bpc3 nts", 256, 2, false, NT, 1, 256, 4, true, 3);                             \
+    SEQ2("SEQ2 K1 u1 bpc1 | fused u4 bpc2 nts", 256, 1, false, NT, 1, 256, 4, true, 2);                             \
+    SEQ2("SEQ2 K1 u1 bpc1 | fused u8 bpc2 nts", 256, 1, false, NT, 1, 256, 8, true, 2);                             \
+    SEQ2("SEQ2 K1 u1 bpc2 | fused u8 bpc2 nts", 256, 1, false, NT, 2, 256, 8, true, 2);                             \
+    SEQ2("SEQ2 K1 b512 u2 bpc1 | fused u8 bpc2 nts", 512, 2, false, NT, 1, 256, 8, true, 2);                        \
+    SEQ2("SEQ2 K1 b512 u1 bpc1 | fused u8 bpc2 nts", 512, 1, false, NT, 1, 256, 8, true, 2);                        \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused b512 u4 bpc1 nts", 256, 2, false, NT, 1, 512, 4, true, 1);                        \
+    SEQ2("SEQ2 K1 u2 bpc1 | fused b512 u8 bpc1 nts", 256, 2, false, NT, 1, 512, 8, true, 1);
+    if (N <= 5000000) { SWEEP(1) } else { SWEEP(2) }
 
     // a valid result block for K2 (and initialised partials for finalize)
     V[1].launch(0);
