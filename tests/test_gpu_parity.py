@@ -343,6 +343,23 @@ def test_large_images_and_garbage_type_high_word(ref, oracle_mod):
     assert comp.getResult().photon_idx == 3999
 
 
+def test_non_finite_inputs_stay_non_finite(ref, oracle_mod):
+    """A NaN or infinite coordinate of a charged molecule poisons the dipole in the reference and here alike, hence every
+    molecular x/y force; the exact flavour is NOT preserved (TwoSum turns an infinite addend into NaN, a plain sum keeps
+    Inf).  Stated so that nobody relies on it; finite inputs never produce non-finite outputs."""
+    for bad in (float("nan"), float("inf")):
+        cfg = _random_cfg(2000, seed=55, photon_at=1999)
+        cfg["position"][17, 0] = bad
+        gpu = gpu_eval(cfg)
+        refout = ref_eval(ref, oracle_mod, cfg)
+        assert not np.isfinite(refout["dipole"][0]) and not np.isfinite(gpu["dipole"][0])
+        assert np.isfinite(refout["dipole"][1]) and gpu["dipole"][1] == pytest.approx(refout["dipole"][1], rel=1e-12)
+        mol = cfg["charge"] != 0
+        mol[1999] = False
+        assert not np.isfinite(gpu["force"][mol, 0]).any() and not np.isfinite(refout["force"][mol, 0]).any()
+        assert np.isfinite(gpu["force"][mol, 1]).all() and np.all(gpu["force"][:1999, 2:] == 0.0)
+
+
 def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     cfg = _random_cfg(200_003, seed=5, photon_at=200_002)
     base = gpu_eval(cfg)
