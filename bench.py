@@ -102,7 +102,8 @@ def timed(ring, steps, warmup, ctx=None):
 
 
 def kernel_times(ring, steps, warmup):
-    """Mean device time per launch of each of the three kernels (HIP events on the launch stream)."""
+    """Mean device time per launch of each kernel (dispatch timestamps via hipExtLaunchKernelGGL start/stop events on the
+    launch stream) and the per-evaluation samples behind the means."""
     for f in ring:
         f.compute.workspace.profile_enable(True)
     run_steps(ring, warmup)
@@ -118,8 +119,8 @@ def kernel_times(ring, steps, warmup):
         tot = [a + b for a, b in zip(tot, ms)]
         launches += n
         f.compute.workspace.profile_enable(False)
-    kernel_times.last_samples = np.concatenate(samples, axis=0) if samples else np.zeros((0, 3))
-    return [t / max(launches, 1) for t in tot], launches
+    samples = np.concatenate(samples, axis=0) if samples else np.zeros((0, 3))
+    return [t / max(launches, 1) for t in tot], launches, samples
 
 
 def percentiles(samples_ms):
@@ -187,7 +188,7 @@ def cpu_baseline(cfg, budget_s):
 def side_measurement(cfg, device, frames, steps, warmup):
     ring = build_ring(cfg, frames, device)
     t = timed(ring, steps, warmup)
-    kt, _ = kernel_times(ring, steps, warmup)
+    kt, _, _ = kernel_times(ring, steps, warmup)
     n = ring[0].n
     out = {"N": n, "frames": frames, "evals_per_s": steps / t, "us_per_eval": 1e6 * t / steps,
            "evaluation_GBps_wall": BYTES_EVAL * n * steps / t / 1e9, "kernel_avg_us": [1e3 * x for x in kt],
@@ -266,9 +267,9 @@ def main():
     elapsed = replicas.max_over_ranks(ctx, elapsed)
     value = ctx.world_size * spec["steps"] / elapsed
 
-    kt, launches = kernel_times(ring, spec["steps"], spec["warmup"])
+    kt, launches, samples = kernel_times(ring, spec["steps"], spec["warmup"])
     roof = roofline_block(n, kt)
-    roof["kernel_time_us_percentiles"] = percentiles(kernel_times.last_samples)
+    roof["kernel_time_us_percentiles"] = percentiles(samples)
     pmc = load_pmc_traffic(n)
     if pmc is not None:
         roof["traffic"] = pmc.get(roof["kernel"], {}).get("hbm_bytes_per_launch")
