@@ -27,7 +27,8 @@ constexpr int kReduceBlock = 256;
 constexpr int kReduceUnroll = 2; // particles per lane and tile; 2 beats 4 by 6 % at 1e6 and 11 % at 3e5, ties at 1e7
 constexpr int kFinalizeBlock = 256;
 constexpr int kMapBlock = 256;
-constexpr int kMapUnroll = 4;
+constexpr int kMapUnroll = 4; // 1024 chunks = 512 particles per tile: the SAME particle range as a reduction tile, so with
+                              // grids that are multiples of 8 tile t is reduced and mapped on the same XCD (t mod 8)
 constexpr int kMaxBlocksPerCU = 16;
 constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
