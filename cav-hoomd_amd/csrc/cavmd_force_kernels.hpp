@@ -248,49 +248,14 @@ struct Scalars
     int photon, nL;
 };
 
-// Folds the `nparts` per-block partials in a FIXED order (thread t takes partials t, t+BLOCK, ... in index order,
-// then the fixed-shape block tree), unwraps the photon and evaluates energies, Dq and the photon force with the
-// reference's operator association (src/CavityForceCompute.cc:169-183, 203-207).  All threads of the block must
-// call it; the result is valid in thread 0 only.  Any block that calls it with the same arguments gets the same
-// bits, which is what lets every block of the fused force map redo it instead of waiting on a separate launch.
-template <class Input, int BLOCK>
-__device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in, unsigned N, unsigned nparts, double Lx,
-                                                                double Ly, double Lz, const DeviceParams& prm,
-                                                                const Partials& part, bool want_energies)
+// From the block total (valid in thread 0) to everything else: renormalise, unwrap the photon and evaluate energies,
+// Dq and the photon force with the reference's operator association (src/CavityForceCompute.cc:169-183, 203-207).
+// `guess` is the speculatively fetched last particle (the driver appends the photon last).
+template <class Input>
+__device__ __forceinline__ Scalars scalars_from_total(Accum acc, const typename Input::Raw& guess, const Input& in,
+                                                      unsigned N, double Lx, double Ly, double Lz,
+                                                      const DeviceParams& prm, bool want_energies)
 {
-    // Speculative fetch of the last particle: the driver appends the photon last (examples/05_advanced_run.py:
-    // 497-505), so this usually removes a dependent memory round trip after the reduction.
-    CAVMD_STAMP(0);
-    const typename Input::Raw guess = in.load((size_t)(N - 1));
-
-    Accum acc;
-    const unsigned s = part.stride;
-    constexpr int BATCH = 4; // partial sets in flight per thread
-    for (unsigned base = 0; base < nparts; base += BATCH * BLOCK)
-    {
-        Accum o[BATCH];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-        {
-            const unsigned p = base + j * BLOCK + threadIdx.x;
-            if (p < nparts)
-            {
-                o[j].hx = part.d[0 * s + p]; o[j].lx = part.d[1 * s + p];
-                o[j].hy = part.d[2 * s + p]; o[j].ly = part.d[3 * s + p];
-                o[j].hz = part.d[4 * s + p]; o[j].lz = part.d[5 * s + p];
-                o[j].sx = part.d[6 * s + p]; o[j].sy = part.d[7 * s + p]; o[j].sz = part.d[8 * s + p];
-                o[j].lmin = part.i[0 * s + p];
-                o[j].lcnt = part.i[1 * s + p];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j)
-            if (base + j * BLOCK < nparts) // block-uniform: skip batches nobody loaded
-                acc.merge(o[j]);           // (a default-constructed Accum is the identity for the ragged last one)
-    }
-    CAVMD_STAMP(1);
-    acc = block_reduce<BLOCK>(acc);
-
     Scalars sc;
     dd_norm(acc.hx, acc.lx);
     dd_norm(acc.hy, acc.ly);
@@ -354,6 +319,51 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
     sc.photon = photon;
     sc.nL = acc.lcnt;
     return sc;
+}
+
+// Folds the `nparts` per-block partials in a FIXED order (thread t takes partials t, t+BLOCK, ... in index order,
+// then the fixed-shape block tree), unwraps the photon and evaluates energies, Dq and the photon force with the
+// reference's operator association (src/CavityForceCompute.cc:169-183, 203-207).  All threads of the block must
+// call it; the result is valid in thread 0 only.  Any block that calls it with the same arguments gets the same
+// bits, which is what lets every block of the fused force map redo it instead of waiting on a separate launch.
+template <class Input, int BLOCK>
+__device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in, unsigned N, unsigned nparts, double Lx,
+                                                                double Ly, double Lz, const DeviceParams& prm,
+                                                                const Partials& part, bool want_energies)
+{
+    // Speculative fetch of the last particle: the driver appends the photon last (examples/05_advanced_run.py:
+    // 497-505), so this usually removes a dependent memory round trip after the reduction.
+    CAVMD_STAMP(0);
+    const typename Input::Raw guess = in.load((size_t)(N - 1));
+
+    Accum acc;
+    const unsigned s = part.stride;
+    constexpr int BATCH = 4; // partial sets in flight per thread
+    for (unsigned base = 0; base < nparts; base += BATCH * BLOCK)
+    {
+        Accum o[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned p = base + j * BLOCK + threadIdx.x;
+            if (p < nparts)
+            {
+                o[j].hx = part.d[0 * s + p]; o[j].lx = part.d[1 * s + p];
+                o[j].hy = part.d[2 * s + p]; o[j].ly = part.d[3 * s + p];
+                o[j].hz = part.d[4 * s + p]; o[j].lz = part.d[5 * s + p];
+                o[j].sx = part.d[6 * s + p]; o[j].sy = part.d[7 * s + p]; o[j].sz = part.d[8 * s + p];
+                o[j].lmin = part.i[0 * s + p];
+                o[j].lcnt = part.i[1 * s + p];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (base + j * BLOCK < nparts) // block-uniform: skip batches nobody loaded
+                acc.merge(o[j]);           // (a default-constructed Accum is the identity for the ragged last one)
+    }
+    CAVMD_STAMP(1);
+    acc = block_reduce<BLOCK>(acc);
+    return scalars_from_total<Input>(acc, guess, in, N, Lx, Ly, Lz, prm, want_energies);
 }
 
 __device__ __forceinline__ void write_result(cavmd_result* __restrict__ res, const Scalars& sc, unsigned N,
@@ -575,6 +585,76 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
     m.photon = s_mi[0];
     m.nL = s_mi[1];
     force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.g, L_typeid, force2, c_first);
+}
+
+// ---- small systems: ONE block, ONE launch ----------------------------------------------------------------------
+// The reference's production system is N = 501 (examples/init-0.gsd, 500 SLURM replicas of it).  At that size two
+// launches are pure latency (~4 us each); a single block that reduces, finalises and maps in one go halves it.  Used
+// below kSmallSystemMaxN particles, where one CU's bandwidth is not yet the limit.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in, unsigned N, double Lx, double Ly, double Lz,
+                                                                    DeviceParams prm, int L_typeid, uint64_t sequence,
+                                                                    cavmd_result* __restrict__ res,
+                                                                    HostResult* __restrict__ res_host,
+                                                                    v2d* __restrict__ force2)
+{
+    __shared__ double s_m[5];
+    __shared__ int s_mi[2];
+    const typename AosInput::Raw guess = in.load((size_t)(N - 1));
+    Accum acc;
+    constexpr int BATCH = 4; // particles in flight per lane
+    for (unsigned base = 0; base < N; base += BATCH * BLOCK)
+    {
+        AosInput::Raw r[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned i = base + j * BLOCK + threadIdx.x;
+            r[j] = in.load(i < N ? i : N - 1); // clamped, the duplicate is masked out below
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+        {
+            const unsigned i = base + j * BLOCK + threadIdx.x;
+            const double rx = AosInput::x(r[j]) + (double)r[j].ix * Lx;
+            const double ry = AosInput::y(r[j]) + (double)r[j].iy * Ly;
+            const double rz = AosInput::z(r[j]) + (double)r[j].iz * Lz;
+            if (i < N)
+                acc.add(i, rx, ry, rz, r[j].c, AosInput::tag(r[j]), L_typeid);
+        }
+    }
+    acc = block_reduce<BLOCK>(acc);
+    const Scalars sc = scalars_from_total<AosInput>(acc, guess, in, N, Lx, Ly, Lz, prm, true);
+    if (threadIdx.x == 0)
+    {
+        s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
+        s_mi[0] = sc.photon;
+        s_mi[1] = sc.nL;
+        write_result(res, sc, N, 1u, sequence);
+        publish_to_host(res_host, sc, N, 1u, sequence);
+    }
+    __syncthreads();
+    const double Dqx = s_m[0], Dqy = s_m[1], Fx = s_m[2], Fy = s_m[3], Fz = s_m[4];
+    const int photon = s_mi[0], nL = s_mi[1];
+    const double ng = -prm.g;
+    const unsigned nchunks = 2 * N;
+    const bool odd = threadIdx.x & 1;
+    const v2d zero = {0.0, 0.0};
+    for (unsigned k = threadIdx.x; k < nchunks; k += BLOCK)
+    {
+        const unsigned p = k >> 1;
+        v2d v = zero;
+        if (photon >= 0)
+        {
+            const double sgc = ng * in.charge[p]; // ((-g) * charge) * Dq, src/CavityForceCompute.cc:194
+            v = (v2d) {sgc * Dqx, sgc * Dqy};
+            const bool typed_L = (nL > 1) && (__double2loint(in.pos2[2 * p + 1].y) == L_typeid);
+            v = (odd || typed_L) ? zero : v;
+            if ((int)p == photon)
+                v = odd ? (v2d) {Fz, 0.0} : (v2d) {Fx, Fy};
+        }
+        force2[k] = v;
+    }
 }
 
 // ---- kernel 3': force map for the snapshot layout (strided (N,3) force + optional potential energy) ---

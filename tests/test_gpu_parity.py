@@ -289,7 +289,12 @@ def test_ragged_sizes_and_photon_positions(ref, oracle_mod, n):
     (N > 65 536 partial-sum truncation, N > 100 000 early-out, N > 262 144 buffer overrun)."""
     for photon_at in sorted({0, n // 2, n - 1}):
         cfg = _random_cfg(n, seed=n * 7 + photon_at, photon_at=photon_at)
-        check_parity(cfg, gpu_eval(cfg), ref_eval(ref, oracle_mod, cfg))
+        refout = ref_eval(ref, oracle_mod, cfg)
+        check_parity(cfg, gpu_eval(cfg), refout)
+        if n <= 4097:
+            # both code paths at small N: the single-block launch (default up to 2048) and the two-launch path
+            check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 0}), refout)
+            check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 8192}), refout)
 
 
 def test_no_photon_zeroes_everything(ref, oracle_mod):
@@ -367,7 +372,7 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     check_parity(cfg, base, refout)
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
                 {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"map_nt_store": 0}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
-                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
+                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"small_system_max_n": 1 << 20}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
         assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))

@@ -1,5 +1,7 @@
 """The pybind11 flavour of the shim (cavitymd._cavitymd): builds in-tree, exposes the reference's method names, refuses to
 run without a GPU (CPU test) and gives the same bits as the ctypes route (GPU test)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,3 +55,27 @@ def test_pybind_route_equals_ctypes_route(ext, ref):
     assert b.getParams()["couplstr"] == 2 * p["couplstr"]
     with pytest.raises(RuntimeError):
         b.computeForces(0, 0, 0, n, 1.0, 1.0, 1.0, 2, 0, 0)
+
+
+@pytest.mark.gpu
+def test_compute_uses_either_binding_with_identical_results(ext):
+    """CavityForceComputeHIP.compute goes through the pybind11 free function when the module is built; the ctypes route
+    on the same workspace must give the same bits."""
+    import cavitymd
+    from cavitymd import compute as compute_mod, synthetic
+    cfg = synthetic.config1(seed=9)
+    p = cfg["params"]
+    pd = cavitymd.ParticleData.from_arrays(cfg["position"], cfg["typeid"], cfg["charge"], cfg["image"], cfg["types"],
+                                           cfg["box"], device="cuda")
+    comp = cavitymd.CavityForceComputeHIP(cavitymd.SystemDefinition(pd), p["omegac"], p["couplstr"], p["phmass"])
+    assert compute_mod._ext is ext or os.environ.get("CAVMD_BINDING", "").lower() == "ctypes"
+    comp.compute(0)
+    a = comp.getForceArray().cpu().numpy().copy()
+    ea = comp.getEnergies()
+    saved, compute_mod._ext = compute_mod._ext, None
+    try:
+        comp.getForceArray().fill_(float("nan"))
+        comp.compute(1)
+        assert np.array_equal(comp.getForceArray().cpu().numpy(), a) and comp.getEnergies() == ea
+    finally:
+        compute_mod._ext = saved
