@@ -66,6 +66,7 @@ struct cavmd_workspace
     int map_nt_store = -1;        // -1 auto (non-temporal from kNtStoreMinN particles up), 0 plain, 1 non-temporal
     int reduce_nt_load = -1;      // -1 auto, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
+    int map_reverse = -1;         // -1 auto, 1: the force map walks its tiles last-to-first, 0: first-to-last
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
     // profiling
     bool profiling = false;
@@ -411,15 +412,19 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     // every other force of the step), and not leaving 32 N dirty bytes behind shortens this kernel's drain and spares
     // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
     const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
+    // Reverse tile order in the force map: the charge lines the reduction touched last are then asked for first.  It only
+    // matters where the per-XCD share of the charges (N bytes) is about the size of an XCD's 4 MiB L2: -3.3 % per
+    // evaluation at N = 4e6, neutral at 3e5 / 1e6 / 2e6 / 1e7 (scripts/ab_tunable.py map_reverse 0 1 ...).
+    const bool map_reverse = ws->map_reverse < 0 ? (N > 2500000 && N <= kChargeTemporalMaxN) : (ws->map_reverse != 0);
     if (ws->fused_finalize)
     {
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
         if (nt_store)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
         else
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
     }
     else
     {
@@ -817,6 +822,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->fused_finalize = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "map_reverse"))
+    {
+        if (value < -1 || value > 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->map_reverse = value;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "small_system_max_n"))
     {
         if (value < 0 || value > (1 << 20))
@@ -841,6 +853,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->reduce_nt_load;
     else if (!strcmp(name, "fused_finalize"))
         *value = ws->fused_finalize;
+    else if (!strcmp(name, "map_reverse"))
+        *value = ws->map_reverse;
     else if (!strcmp(name, "small_system_max_n"))
         *value = ws->small_system_max_n;
     else

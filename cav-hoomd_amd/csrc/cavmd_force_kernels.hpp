@@ -442,7 +442,8 @@ struct MapScalars
 template <int BLOCK, int UNROLL, bool NT, bool PRE>
 __device__ __forceinline__ void force_map_body(const MapScalars m, const double* __restrict__ charge,
                                                const v2d* __restrict__ pos2, unsigned N, double g, int L_typeid,
-                                               v2d* __restrict__ force2, const double (&c_first)[UNROLL])
+                                               v2d* __restrict__ force2, const double (&c_first)[UNROLL],
+                                               bool reverse = false)
 {
     constexpr unsigned TILE = BLOCK * UNROLL;
     const double ng = -g;
@@ -462,11 +463,15 @@ __device__ __forceinline__ void force_map_body(const MapScalars m, const double*
 
     if (m.nL <= 1)
     {
-        for (unsigned t = blockIdx.x; t < full_tiles; t += gridDim.x)
+        // Tiles blockIdx.x, blockIdx.x + grid, ...; `reverse` walks the same tiles from the last to the first, so that
+        // the charge lines the reduction touched most recently (same XCD, see cavmd_capi.hip) are asked for first.
+        const unsigned count = blockIdx.x < full_tiles ? (full_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        for (unsigned j = 0; j < count; ++j)
         {
+            const unsigned t = blockIdx.x + (reverse ? count - 1 - j : j) * gridDim.x;
             const size_t base = (size_t)t * TILE + threadIdx.x;
             double c[UNROLL];
-            if (PRE && t == blockIdx.x)
+            if (PRE && j == 0)
             {
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u)
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
                                                                     Partials part, uint64_t sequence,
                                                                     cavmd_result* __restrict__ res,
                                                                     HostResult* __restrict__ res_host,
-                                                                    v2d* __restrict__ force2)
+                                                                    v2d* __restrict__ force2, bool reverse)
 {
     __shared__ double s_m[5];
     __shared__ int s_mi[2];
@@ -561,7 +566,9 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
         const unsigned full_tiles = (unsigned)((2 * (size_t)N) / TILE);
         if (blockIdx.x < full_tiles)
         {
-            const size_t base = (size_t)blockIdx.x * TILE + threadIdx.x;
+            const unsigned count = (full_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+            const unsigned t0 = blockIdx.x + (reverse ? count - 1 : 0) * gridDim.x;
+            const size_t base = (size_t)t0 * TILE + threadIdx.x;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
                 c_first[u] = in.charge[(base + (size_t)u * BLOCK) >> 1];
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
     m.Dqx = s_m[0]; m.Dqy = s_m[1]; m.Fx = s_m[2]; m.Fy = s_m[3]; m.Fz = s_m[4];
     m.photon = s_mi[0];
     m.nL = s_mi[1];
-    force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.g, L_typeid, force2, c_first);
+    force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.g, L_typeid, force2, c_first, reverse);
 }
 
 // ---- small systems: ONE block, ONE launch ----------------------------------------------------------------------

@@ -287,7 +287,7 @@ int main(int argc, char** argv)
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_nt1_of(f), n, L, L, L, 2, part); \
                      else                                                                                               \
                          hipLaunchKernelGGL((dipole_partials_kernel<AosInput, KB, KU, KP>), dim3(g1), dim3(KB), 0, st, in_of(f), n, L, L, L, 2, part); \
-                     hipLaunchKernelGGL((force_map_aos_fused_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, in_of(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f]); \
+                     hipLaunchKernelGGL((force_map_aos_fused_kernel<MB, MU, MNT>), dim3(grid(2 * N, MB * MU, MBPC)), dim3(MB), 0, st, in_of(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f], false); \
                  }, {}})
     // NT = charge-load policy of the reduction (1 below 5e6 particles, 2 above), stores non-temporal
 #define SWEEP(NT)                                                                                                   \

@@ -230,6 +230,7 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "map_nt_store"         -1..1   -1 auto by N, 0 plain, 1 non-temporal force stores
  *   "reduce_nt_load"       -1..2   -1 auto by N, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
+ *   "map_reverse"          -1..1   -1 auto by N, 1: the force map walks its tiles last-to-first, 0: first-to-last
  *   "small_system_max_n"   0..2^20 at or below this N one single-block launch does the whole evaluation (0 = never)
  * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value.  None of them changes results
  * beyond the last bit of the dipole (different but fixed summation trees). */

@@ -372,7 +372,8 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     check_parity(cfg, base, refout)
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
                 {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"map_nt_store": 0}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
-                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"small_system_max_n": 1 << 20}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
+                {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"small_system_max_n": 1 << 20}, {"map_reverse": 1}, {"map_reverse": 0, "map_blocks_per_cu": 1},
+                {"map_reverse": 1, "map_blocks_per_cu": 7}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
         assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))
