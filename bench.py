@@ -163,6 +163,17 @@ def load_pmc_traffic(workload_n):
         return None
 
 
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, budget_s):
     """The oracle (port of the reference CPU path) on one host thread, bounded sample of the same workload."""
     import oracle
@@ -182,7 +193,7 @@ def cpu_baseline(cfg, budget_s):
             "sample": f"{out[best]['iters']} evaluations of frame 0 of the same workload (N={n}), oracle/cavity_ref.c "
                       f"gcc -O2 -ffp-contract=off, 1 thread, {out[best]['seconds']:.1f} s",
             "GBps_equiv": BYTES_EVAL * n * out[best]["evals_per_s"] / 1e9,
-            "O3_evals_per_s": out["O3"]["evals_per_s"], "host_cpus": os.cpu_count()}
+            "O3_evals_per_s": out["O3"]["evals_per_s"], "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model()}
 
 
 def side_measurement(cfg, device, frames, steps, warmup):

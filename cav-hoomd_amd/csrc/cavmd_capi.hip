@@ -510,21 +510,39 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
     const unsigned n = (unsigned)N;
     const DeviceParams dp = derive(params);
 
-    const unsigned g1 = grid_for(N, kReduceBlock * kReduceUnroll, ws->num_cu, ws->reduce_blocks_per_cu);
-    int st = ls.launch(0, dipole_partials_kernel<StridedInput, kReduceBlock, kReduceUnroll, false>, g1, kReduceBlock, in,
-                       n, Lx, Ly, Lz, L_typeid, part);
+    // same tile-depth rule as cavmd_compute_hoomd, so that both layouts share one summation tree (and give equal bits)
+    int unroll = kReduceUnroll;
+    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu / 4)
+        unroll >>= 1;
+    const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    int st;
+    if (unroll == 2)
+        st = ls.launch(0, dipole_partials_kernel<StridedInput, kReduceBlock, 2, false>, g1, kReduceBlock, in, n, Lx, Ly, Lz,
+                       L_typeid, part);
+    else
+        st = ls.launch(0, dipole_partials_kernel<StridedInput, kReduceBlock, 1, false>, g1, kReduceBlock, in, n, Lx, Ly, Lz,
+                       L_typeid, part);
     if (st != CAVMD_OK)
         return st;
     ws->sequence += 1;
-    st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
-                   part, ws->sequence, ws->d_result, ws->h_result_dev);
-    if (st != CAVMD_OK)
-        return st;
-    const unsigned g2 = grid_for(N, kMapBlock, ws->num_cu, 8);
-    const cavmd_result* res = ws->d_result;
-    st = ls.launch(2, force_map_strided_kernel<kMapBlock>, g2, kMapBlock, in, n, params->couplstr, L_typeid, res,
-                   reinterpret_cast<char*>(d_force), force_stride, reinterpret_cast<char*>(d_potential_energy),
-                   potential_energy_stride);
+    char* f_out = reinterpret_cast<char*>(d_force);
+    char* pe_out = reinterpret_cast<char*>(d_potential_energy);
+    const unsigned g2 = grid_for(N, kMapBlock * 4, ws->num_cu, ws->map_blocks_per_cu);
+    if (ws->fused_finalize)
+    {
+        st = ls.launch(2, force_map_strided_fused_kernel<kMapBlock>, g2, kMapBlock, in, n, g1, Lx, Ly, Lz, dp, L_typeid, part,
+                       ws->sequence, ws->d_result, ws->h_result_dev, f_out, force_stride, pe_out, potential_energy_stride);
+    }
+    else
+    {
+        st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
+                       part, ws->sequence, ws->d_result, ws->h_result_dev);
+        if (st != CAVMD_OK)
+            return st;
+        const cavmd_result* res = ws->d_result;
+        st = ls.launch(2, force_map_strided_kernel<kMapBlock>, g2, kMapBlock, in, n, params->couplstr, L_typeid, res,
+                       f_out, force_stride, pe_out, potential_energy_stride);
+    }
     if (st != CAVMD_OK)
         return st;
     ls.commit();

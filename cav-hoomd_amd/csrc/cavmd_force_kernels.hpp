@@ -75,15 +75,15 @@ struct StridedInput
     {
         Raw r;
         const double* p = reinterpret_cast<const double*>(pos + i * pos_stride);
-        r.px = p[0];
-        r.py = p[1];
-        r.pz = p[2];
-        r.c = *reinterpret_cast<const double*>(chg + i * chg_stride);
+        r.px = __builtin_nontemporal_load(p + 0);
+        r.py = __builtin_nontemporal_load(p + 1);
+        r.pz = __builtin_nontemporal_load(p + 2);
+        r.c = *reinterpret_cast<const double*>(chg + i * chg_stride); // temporal: the force map reads it again
         const int* im = reinterpret_cast<const int*>(img + i * img_stride);
-        r.ix = im[0];
-        r.iy = im[1];
-        r.iz = im[2];
-        r.t = *reinterpret_cast<const int*>(tid + i * tid_stride);
+        r.ix = __builtin_nontemporal_load(im + 0);
+        r.iy = __builtin_nontemporal_load(im + 1);
+        r.iz = __builtin_nontemporal_load(im + 2);
+        r.t = __builtin_nontemporal_load(reinterpret_cast<const int*>(tid + i * tid_stride));
         return r;
     }
     static __device__ __forceinline__ double x(const Raw& r) { return r.px; }
@@ -664,50 +664,107 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
     }
 }
 
-// ---- kernel 3': force map for the snapshot layout (strided (N,3) force + optional potential energy) ---
+// ---- force map for the snapshot layout (strided (N,3) force + optional potential energy) ------------------------
+// One particle per lane; UNROLL charges are loaded before the stores.  When the force rows are packed (stride 24) a
+// wave's 64 rows are one contiguous 1.5 KB run, so the three 8-byte stores per lane still fill whole lines.
+template <int BLOCK, int UNROLL>
+__device__ __forceinline__ void force_map_strided_body(const MapScalars m, const StridedInput& in, unsigned N, double g,
+                                                       int L_typeid, char* __restrict__ force, size_t force_stride,
+                                                       char* __restrict__ pe, size_t pe_stride)
+{
+    const double ng = -g;
+    constexpr size_t TILE = (size_t)BLOCK * UNROLL;
+    const size_t tiles = ((size_t)N + TILE - 1) / TILE;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x)
+    {
+        const size_t base = t * TILE + threadIdx.x;
+        double c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const size_t i = base + (size_t)u * BLOCK;
+            c[u] = (m.photon >= 0 && i < N) ? *reinterpret_cast<const double*>(in.chg + i * in.chg_stride) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const size_t i = base + (size_t)u * BLOCK;
+            if (i >= N)
+                continue;
+            double fx = 0.0, fy = 0.0, fz = 0.0;
+            if (m.photon >= 0)
+            {
+                const double s = ng * c[u]; // ((-g) * charge) * Dq, src/CavityForceCompute.cc:194
+                fx = s * m.Dqx;
+                fy = s * m.Dqy;
+                if (m.nL > 1 && *reinterpret_cast<const int*>(in.tid + i * in.tid_stride) == L_typeid)
+                {
+                    fx = 0.0;
+                    fy = 0.0;
+                }
+                if ((int)i == m.photon)
+                {
+                    fx = m.Fx;
+                    fy = m.Fy;
+                    fz = m.Fz;
+                }
+            }
+            double* f = reinterpret_cast<double*>(force + i * force_stride);
+            __builtin_nontemporal_store(fx, f + 0);
+            __builtin_nontemporal_store(fy, f + 1);
+            __builtin_nontemporal_store(fz, f + 2);
+            if (pe)
+                __builtin_nontemporal_store(0.0, reinterpret_cast<double*>(pe + i * pe_stride));
+        }
+    }
+}
+
+// three-launch variant (scalars from the result block)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void force_map_strided_kernel(StridedInput in, unsigned N, double g, int L_typeid,
                                                                   const cavmd_result* __restrict__ res,
                                                                   char* __restrict__ force, size_t force_stride,
                                                                   char* __restrict__ pe, size_t pe_stride)
 {
-    const double Dqx = res->Dq[0], Dqy = res->Dq[1];
-    const int photon = res->photon_idx;
-    const int nL = res->n_photon_typed;
-    const double Fx = res->photon_force[0], Fy = res->photon_force[1], Fz = res->photon_force[2];
-    const double ng = -g;
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (size_t)gridDim.x * BLOCK)
+    MapScalars m;
+    m.Dqx = res->Dq[0]; m.Dqy = res->Dq[1];
+    m.Fx = res->photon_force[0]; m.Fy = res->photon_force[1]; m.Fz = res->photon_force[2];
+    m.photon = res->photon_idx;
+    m.nL = res->n_photon_typed;
+    force_map_strided_body<BLOCK, 4>(m, in, N, g, L_typeid, force, force_stride, pe, pe_stride);
+}
+
+// two-launch variant: the same prologue as force_map_aos_fused_kernel
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void force_map_strided_fused_kernel(StridedInput in, unsigned N, unsigned nparts,
+                                                                        double Lx, double Ly, double Lz, DeviceParams prm,
+                                                                        int L_typeid, Partials part, uint64_t sequence,
+                                                                        cavmd_result* __restrict__ res,
+                                                                        HostResult* __restrict__ res_host,
+                                                                        char* __restrict__ force, size_t force_stride,
+                                                                        char* __restrict__ pe, size_t pe_stride)
+{
+    __shared__ double s_m[5];
+    __shared__ int s_mi[2];
+    const Scalars sc = reduce_partials_and_finalize<StridedInput, BLOCK>(in, N, nparts, Lx, Ly, Lz, prm, part,
+                                                                         blockIdx.x == 0);
+    if (threadIdx.x == 0)
     {
-        double fx = 0.0, fy = 0.0, fz = 0.0;
-        if (photon >= 0)
+        s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
+        s_mi[0] = sc.photon;
+        s_mi[1] = sc.nL;
+        if (blockIdx.x == 0)
         {
-            const double c = *reinterpret_cast<const double*>(in.chg + i * in.chg_stride);
-            const double s = ng * c;
-            fx = s * Dqx;
-            fy = s * Dqy;
-            if (nL > 1)
-            {
-                const int t = *reinterpret_cast<const int*>(in.tid + i * in.tid_stride);
-                if (t == L_typeid)
-                {
-                    fx = 0.0;
-                    fy = 0.0;
-                }
-            }
-            if ((int)i == photon)
-            {
-                fx = Fx;
-                fy = Fy;
-                fz = Fz;
-            }
+            write_result(res, sc, N, nparts, sequence);
+            publish_to_host(res_host, sc, N, nparts, sequence);
         }
-        double* f = reinterpret_cast<double*>(force + i * force_stride);
-        f[0] = fx;
-        f[1] = fy;
-        f[2] = fz;
-        if (pe)
-            *reinterpret_cast<double*>(pe + i * pe_stride) = 0.0;
     }
+    __syncthreads();
+    MapScalars m;
+    m.Dqx = s_m[0]; m.Dqy = s_m[1]; m.Fx = s_m[2]; m.Fy = s_m[3]; m.Fz = s_m[4];
+    m.photon = s_mi[0];
+    m.nL = s_mi[1];
+    force_map_strided_body<BLOCK, 4>(m, in, N, prm.g, L_typeid, force, force_stride, pe, pe_stride);
 }
 
 } // namespace cavmd

@@ -507,11 +507,12 @@ def test_snapshot_layout_entry_point(ref, oracle_mod, hoomd_views):
 
 
 def test_both_layouts_give_identical_bits():
-    cfg = _random_cfg(123_457, seed=77, photon_at=123_456)
-    a = gpu_eval(cfg)
-    b = _soa_eval(cfg, hoomd_views=False)
-    assert np.array_equal(a["dipole"], b["dipole"]) and np.array_equal(a["energies"], b["energies"])
-    assert np.array_equal(a["force"], b["force"])
+    for n, tun in ((123_457, None), (20_001, None), (1_500, {"small_system_max_n": 0})):
+        cfg = _random_cfg(n, seed=77, photon_at=n - 1)
+        a = gpu_eval(cfg, tun)     # (the single-block path exists for the AoS layout only: switched off for the small case)
+        b = _soa_eval(cfg, hoomd_views=False)
+        assert np.array_equal(a["dipole"], b["dipole"]) and np.array_equal(a["energies"], b["energies"])
+        assert np.array_equal(a["force"], b["force"])
 
 
 def test_randomised_small_systems_one_workspace(ref, oracle_mod):
