@@ -100,9 +100,13 @@ __global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __r
 
     double re = 0.0, im = 0.0;
     const unsigned ntiles = (N + kWave - 1) / kWave;
-    const unsigned gw = blockIdx.x * NW + wave, GW = gridDim.x * NW;
+    // wave index made provably uniform so that the particle addresses below are SGPR values (scalar loads)
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    const unsigned gw = blockIdx.x * NW + wave_u, GW = gridDim.x * NW;
+    const double ksum = (fabs(kx) + fabs(ky)) + fabs(kz);
     for (unsigned tile = gw; tile < ntiles; tile += GW)
     {
+        // lane = particle: one coalesced round, used for the tile's coordinate bound and for the rare slow path
         const size_t i = (size_t)tile * kWave + lane;
         double px = 0.0, py = 0.0, pz = 0.0;
         if (i < N)
@@ -114,17 +118,65 @@ __global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __r
         }
         const unsigned left = N - tile * kWave;
         const int cnt = left < (unsigned)kWave ? (int)left : kWave; // wave-uniform
-        for (int j = 0; j < cnt; ++j)
+        // |k . r| <= (|kx| + |ky| + |kz|) * max|coordinate|: ONE range check per tile instead of one per particle
+        double m = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
+        m = fmax(m, dpp_f64<0xB1, 0xF>(m, 0.0));
+        m = fmax(m, dpp_f64<0x4E, 0xF>(m, 0.0));
+        m = fmax(m, dpp_f64<0x124, 0xF>(m, 0.0));
+        m = fmax(m, dpp_f64<0x128, 0xF>(m, 0.0));
+        m = fmax(m, __shfl_xor(m, 16, kWave));
+        m = fmax(m, __shfl_xor(m, 32, kWave));
+        const bool all_finite = !__any(!(fabs(px) < 1.0e300) || !(fabs(py) < 1.0e300) || !(fabs(pz) < 1.0e300));
+        if (all_finite && !__any(!(ksum * m < 1.0e8)))
         {
-            const double x = readlane_f64(px, j), y = readlane_f64(py, j), z = readlane_f64(pz, j);
-            const double kr = (x * kx + y * ky) + z * kz;
-            double s, c;
-            if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
-                sincos(kr, &s, &c);
-            else
-                sincos_reduced(coef, kr, s, c);
-            re += c;
-            im += s;
+            // fast path: every |k . r| of this tile is below 1e8.  The coordinates come through the scalar cache
+            // (s_load on a uniform address): broadcasting them costs no VALU issue slots.
+            const char* base = pos + (size_t)tile * kWave * pos_stride;
+            constexpr int PU = 4; // particles per iteration: amortises the loop and lets independent sincos chains interleave
+            int j = 0;
+            for (; j + PU <= cnt; j += PU)
+            {
+                double x[PU], y[PU], z[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                {
+                    const double* p = reinterpret_cast<const double*>(base + (size_t)(j + u) * pos_stride);
+                    x[u] = p[0];
+                    y[u] = p[1];
+                    z[u] = p[2];
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+                {
+                    double sn, cs;
+                    sincos_reduced(coef, (x[u] * kx + y[u] * ky) + z[u] * kz, sn, cs);
+                    re += cs;
+                    im += sn;
+                }
+            }
+            for (; j < cnt; ++j)
+            {
+                const double* p0 = reinterpret_cast<const double*>(base + (size_t)j * pos_stride);
+                double s0, c0;
+                sincos_reduced(coef, (p0[0] * kx + p0[1] * ky) + p0[2] * kz, s0, c0);
+                re += c0;
+                im += s0;
+            }
+        }
+        else
+        {
+            for (int j = 0; j < cnt; ++j)
+            {
+                const double x = readlane_f64(px, j), y = readlane_f64(py, j), z = readlane_f64(pz, j);
+                const double kr = (x * kx + y * ky) + z * kz;
+                double sn, cs;
+                if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
+                    sincos(kr, &sn, &cs);
+                else
+                    sincos_reduced(coef, kr, sn, cs);
+                re += cs;
+                im += sn;
+            }
         }
     }
     s_acc[wave][0][lane] = re;
