@@ -189,11 +189,24 @@ def cpu_baseline(cfg, budget_s):
         out[opt] = {"evals_per_s": iters / t, "iters": iters, "seconds": t}
     best = "O2"
     n = len(cfg["charge"])
+    # courtesy: the same passes on every core of this host (OpenMP; NOT the reference's algorithm -- it is single-threaded)
+    try:
+        omp = oracle.AllCoresCourtesy()
+        p = oracle.RefOracle("O2").make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+        args = (pos4, cfg["charge"], cfg["image"], cfg["box"], cfg["L_typeid"], p)
+        t1 = omp.time_evaluations(*args, 5) / 5
+        iters = int(max(5, min(5000, 3.0 / max(t1, 1e-9))))
+        t = omp.time_evaluations(*args, iters)
+        courtesy = {"evals_per_s": iters / t, "threads": omp.threads(), "iters": iters,
+                    "note": "OpenMP variant, parallel reduction order: not the reference's algorithm, not an oracle"}
+    except OSError as e:  # no libgomp on this host
+        courtesy = {"error": str(e)}
     return {"value": out[best]["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"{out[best]['iters']} evaluations of frame 0 of the same workload (N={n}), oracle/cavity_ref.c "
                       f"gcc -O2 -ffp-contract=off, 1 thread, {out[best]['seconds']:.1f} s",
             "GBps_equiv": BYTES_EVAL * n * out[best]["evals_per_s"] / 1e9,
-            "O3_evals_per_s": out["O3"]["evals_per_s"], "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model()}
+            "O3_evals_per_s": out["O3"]["evals_per_s"], "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model(),
+            "all_cores_courtesy": courtesy}
 
 
 def side_measurement(cfg, device, frames, steps, warmup):

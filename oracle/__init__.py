@@ -39,7 +39,7 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libcavref.so")
     src = os.path.join(_HERE, "cavity_ref.c")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) \
-        or not os.path.exists(os.path.join(_HERE, "libcavref_O3.so"))
+        or not os.path.exists(os.path.join(_HERE, "libcavref_O3.so")) or not os.path.exists(os.path.join(_HERE, "libcavomp.so"))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
     return so
@@ -162,3 +162,72 @@ class RefOracle:
             self.lib.cavref_time_evaluations(pos4.shape[0], pos4.ctypes.data, charge.ctypes.data, image.ctypes.data,
                                              float(box_L[0]), float(box_L[1]), float(box_L[2]), int(L_typeid),
                                              ctypes.byref(self._params(params)), force.ctypes.data, int(iters)))
+
+
+def allowed_cpus() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(quota / int(g.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+class AllCoresCourtesy:
+    """OpenMP variant of the same passes (oracle/cavity_omp.c): a courtesy 'every core of the host' figure for bench.py.
+    NOT the reference's algorithm (parallel reduction order) and never used as an oracle."""
+
+    def __init__(self):
+        build()
+        # libgomp reads these when it is loaded: idle threads must sleep, not spin (shared hosts are oversubscribed)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("OMP_PROC_BIND", "false")
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(allowed_cpus(), 64)))
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "libcavomp.so"))
+        vp, dbl, ci, cu = ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_uint
+        self.lib.cavomp_threads.restype = ci
+        self.lib.cavomp_set_threads.argtypes = [ci]
+        self.lib.cavomp_set_threads.restype = None
+        # libgomp may already have been initialised by another library (torch): size the team through the API as well
+        self.lib.cavomp_set_threads(min(allowed_cpus(), 64))
+        self.lib.cavomp_compute.argtypes = [cu, vp, vp, vp, dbl, dbl, dbl, ci, ctypes.POINTER(_RefParams), vp, vp]
+        self.lib.cavomp_compute.restype = None
+        self.lib.cavomp_time.argtypes = [cu, vp, vp, vp, dbl, dbl, dbl, ci, ctypes.POINTER(_RefParams), vp, ci]
+        self.lib.cavomp_time.restype = dbl
+
+    def threads(self) -> int:
+        return int(self.lib.cavomp_threads())
+
+    def compute(self, pos4, charge, image, box_L, L_typeid, params):
+        pos4 = np.ascontiguousarray(pos4, dtype=np.float64)
+        charge = np.ascontiguousarray(charge, dtype=np.float64)
+        image = np.ascontiguousarray(image, dtype=np.int32)
+        force = np.empty_like(pos4)
+        e = np.zeros(3)
+        p = _RefParams(params["omegac"], params["couplstr"], params["K"], params["phmass"])
+        self.lib.cavomp_compute(pos4.shape[0], pos4.ctypes.data, charge.ctypes.data, image.ctypes.data, float(box_L[0]),
+                                float(box_L[1]), float(box_L[2]), int(L_typeid), ctypes.byref(p), force.ctypes.data,
+                                e.ctypes.data)
+        return {"force": force, "energies": e}
+
+    def time_evaluations(self, pos4, charge, image, box_L, L_typeid, params, iters: int) -> float:
+        pos4 = np.ascontiguousarray(pos4, dtype=np.float64)
+        charge = np.ascontiguousarray(charge, dtype=np.float64)
+        image = np.ascontiguousarray(image, dtype=np.int32)
+        force = np.empty_like(pos4)
+        p = _RefParams(params["omegac"], params["couplstr"], params["K"], params["phmass"])
+        return float(self.lib.cavomp_time(pos4.shape[0], pos4.ctypes.data, charge.ctypes.data, image.ctypes.data,
+                                          float(box_L[0]), float(box_L[1]), float(box_L[2]), int(L_typeid),
+                                          ctypes.byref(p), force.ctypes.data, int(iters)))

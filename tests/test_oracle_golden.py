@@ -199,3 +199,22 @@ def test_no_photon_and_empty(ref, oracle_mod):
     empty = ref.compute(np.zeros((0, 4)), np.zeros(0), np.zeros((0, 3), dtype=np.int32), (1, 1, 1), 2,
                         ref.make_params(1, 1, 1))
     assert empty["photon_idx"] == -1 and empty["force"].shape == (0, 4)
+
+
+def test_all_cores_courtesy_variant_agrees_to_rounding(ref, oracle_mod):
+    """oracle/cavity_omp.c is only a timing courtesy for bench.py, but it must still compute the same physics."""
+    rng = np.random.default_rng(8)
+    n = 20_000
+    L = (60.0, 60.0, 60.0)
+    pos = rng.uniform(-30, 30, (n, 3))
+    tid = (np.arange(n) % 2).astype(np.int32)
+    tid[-1] = 2
+    charge = rng.uniform(-1, 1, n)
+    charge[-1] = 0.0
+    image = rng.integers(-1, 2, (n, 3)).astype(np.int32)
+    pos4 = oracle_mod.pack_pos(pos, tid)
+    p = ref.make_params(0.0091, 1e-3, 1.0)
+    a = ref.compute(pos4, charge, image, L, 2, p)
+    b = oracle_mod.AllCoresCourtesy().compute(pos4, charge, image, L, 2, p)
+    assert np.allclose(a["energies"], b["energies"], rtol=1e-10)
+    assert np.abs(a["force"] - b["force"]).max() <= 1e-10 * np.abs(a["force"]).max()
