@@ -334,9 +334,12 @@ def main():
             extras["1e6_energy_poll_every_step"] = energy_poll_measurement(cfg, ctx.device, spec["frames"], spec["steps"],
                                                                            spec["warmup"])
             line["extras"] = extras
-    if ctx.rank == 0:
-        print(json.dumps(line), flush=True)
+    rank = ctx.rank
     replicas.shutdown(ctx)
+    if rank == 0:
+        # last thing on stdout (RCCL prints a version banner at init; nothing may follow the JSON line)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
