@@ -102,6 +102,24 @@ struct DeviceParams
     double g2K;  // g * g / K        (src/CavityForceCompute.cc:176)
 };
 
+// The speculatively fetched last particle (the driver appends the photon last), as plain scalars: handing the
+// layout's whole Raw aggregate through the prologue made hipcc keep it in a stack object (52 B of scratch stores per
+// thread of every block of the fused force map: 1.19x its algorithmic HBM traffic at N = 1e6).
+struct PhotonRow
+{
+    double x, y, z;
+    int ix, iy, iz;
+};
+template <class Input>
+__device__ __forceinline__ PhotonRow photon_row(const Input& in, size_t i)
+{
+    const typename Input::Raw r = in.load(i);
+    PhotonRow p;
+    p.x = Input::x(r); p.y = Input::y(r); p.z = Input::z(r);
+    p.ix = r.ix; p.iy = r.iy; p.iz = r.iz;
+    return p;
+}
+
 // Where the per-block partials live (SoA so the finalize kernel reads them coalesced).
 struct Partials
 {
@@ -252,7 +270,7 @@ struct Scalars
 // Dq and the photon force with the reference's operator association (src/CavityForceCompute.cc:169-183, 203-207).
 // `guess` is the speculatively fetched last particle (the driver appends the photon last).
 template <class Input>
-__device__ __forceinline__ Scalars scalars_from_total(Accum acc, const typename Input::Raw& guess, const Input& in,
+__device__ __forceinline__ Scalars scalars_from_total(Accum acc, const PhotonRow guess, const Input& in,
                                                       unsigned N, double Lx, double Ly, double Lz,
                                                       const DeviceParams& prm, bool want_energies)
 {
@@ -272,20 +290,27 @@ __device__ __forceinline__ Scalars scalars_from_total(Accum acc, const typename 
     {
         if (photon >= 0)
         {
-            typename Input::Raw r = guess;
+            // field-by-field select between the speculative row and the fallback load
+            double px = guess.x, py = guess.y, pz = guess.z;
+            int pix = guess.ix, piy = guess.iy, piz = guess.iz;
             if ((unsigned)photon != N - 1)
-                r = in.load((size_t)photon);
-            qx = Input::x(r) + (double)r.ix * Lx;
-            qy = Input::y(r) + (double)r.iy * Ly;
-            qz = Input::z(r) + (double)r.iz * Lz;
+            {
+                const PhotonRow r = photon_row(in, (size_t)photon);
+                px = r.x; py = r.y; pz = r.z;
+                pix = r.ix; piy = r.iy; piz = r.iz;
+            }
+            qx = px + (double)pix * Lx;
+            qy = py + (double)piy * Ly;
+            qz = pz + (double)piz * Lz;
             if (acc.lcnt > 1)
             {
                 // Degenerate input (the driver enforces exactly one 'L', examples/05_advanced_run.py:548-550): the
                 // reference skips only the FIRST L-typed particle in the dipole (src/CavityForceCompute.cc:122), so
-                // the later ones are added back here.
-                dx += acc.sx - r.c * qx;
-                dy += acc.sy - r.c * qy;
-                dz += acc.sz - r.c * qz;
+                // the later ones are added back here.  (Rare: the photon's charge is fetched here, not speculatively.)
+                const double pc = in.load((size_t)photon).c;
+                dx += acc.sx - pc * qx;
+                dy += acc.sy - pc * qy;
+                dz += acc.sz - pc * qz;
             }
             if (want_energies)
             {
@@ -334,7 +359,7 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
     // Speculative fetch of the last particle: the driver appends the photon last (examples/05_advanced_run.py:
     // 497-505), so this usually removes a dependent memory round trip after the reduction.
     CAVMD_STAMP(0);
-    const typename Input::Raw guess = in.load((size_t)(N - 1));
+    const PhotonRow guess = photon_row(in, (size_t)(N - 1));
 
     Accum acc;
     const unsigned s = part.stride;
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
 {
     __shared__ double s_m[5];
     __shared__ int s_mi[2];
-    const typename AosInput::Raw guess = in.load((size_t)(N - 1));
+    const PhotonRow guess = photon_row(in, (size_t)(N - 1));
     Accum acc;
     constexpr int BATCH = 4; // particles in flight per lane
     for (unsigned base = 0; base < N; base += BATCH * BLOCK)

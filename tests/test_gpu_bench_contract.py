@@ -52,3 +52,20 @@ def test_two_rank_rehearsal():
     # whole-job aggregate: two replicas' evaluations over the slowest rank's time
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_plain_gpus2_form_self_launches():
+    """The driver's command form: `python bench.py --gpus 2 ...` with NO outer torch.distributed.run.  bench.py starts
+    its own two rank processes (before importing torch), relays rank 0's JSON line last and exits 0.  Both ranks share
+    the one visible GPU here, so the control collectives run over gloo (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, CAVMD_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+           "--n-molecular", "200000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("{"), out.stdout[-500:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["replicas"] == 2 and d["config"]["collectives_on_data_path"] == 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

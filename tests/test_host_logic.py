@@ -119,3 +119,23 @@ def test_replica_planning():
     bad[9] = 99.0
     with pytest.raises(RuntimeError, match="version"):
         replicas.unpack_block(bad)
+
+
+def test_bench_self_launch_plumbing_without_a_gpu():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two rank processes itself and returns their worst
+    exit code.  Without a GPU every rank refuses to run (the product has no CPU path), which is exactly what makes the
+    plumbing observable here: two refusals on stderr, a non-zero exit code, no JSON line."""
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CAVMD_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n-molecular", "1000"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    import torch
+    if torch.cuda.is_available():
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("{")
+    else:
+        assert out.returncode != 0
+        assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
