@@ -24,6 +24,7 @@ CAVMD_ERR_NO_DEVICE = -2
 CAVMD_ERR_CAPACITY = -3
 CAVMD_ERR_BAD_PARAMS = -4
 CAVMD_ERR_NOT_COMPUTED = -5
+CAVMD_ERR_SYNC_TIMEOUT = -6
 
 
 class CavmdError(RuntimeError):
@@ -68,7 +69,7 @@ _lock = threading.Lock()
 
 def build(force: bool = False) -> str:
     """Compile libcavmd.so for gfx950 with hipcc (cross-compiles without a GPU).  Idempotent."""
-    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".hpp")) and f != "microbench.hip"]
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".hpp")) and not f.startswith("microbench")]
     srcs.append(os.path.normpath(os.path.join(CSRC_DIR, "..", "..", "include", "cavmd.h")))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

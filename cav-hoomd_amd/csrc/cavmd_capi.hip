@@ -37,6 +37,8 @@ constexpr int kSmallBlock = 256;
 constexpr int kSmallSystemMaxN = 2048;         // single-block path wins below ~3000 particles (7.4 vs 11.0 us at N = 501, 9.2 vs 11.4 at 2001)
 constexpr size_t kNtStoreMinN = 200000;       // force stores: neutral at 1e5, -3.6 % at 3e5, -4.3 % at 1e6, -5.8 % at 1e7
 constexpr size_t kChargeTemporalMaxN = 5000000; // measured crossover: temporal charge loads win up to 4e6, tie at 6e6, lose at 1e7
+constexpr int kPersistBlock = 256;
+constexpr size_t kPersistMaxLds = 156 * 1024; // dynamic LDS of the single-launch kernel (charges of a block's tiles); 160 KiB per CU
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
 static_assert(sizeof(cavmd_int3) == 12, "int3 layout");
@@ -68,6 +70,11 @@ struct cavmd_workspace
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     int map_reverse = -1;         // -1 auto, 1: the force map walks its tiles last-to-first, 0: first-to-last
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
+    int persistent = -1;          // -1 auto, 0 never, 1 whenever the charges of a block's tiles fit in LDS: ONE launch per evaluation
+    // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
+    unsigned long long* d_granules = nullptr;
+    unsigned* d_epoch = nullptr;
+    bool captured = false; // some evaluation was enqueued into a stream capture: the host-side flag protocol is off
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events; // kEventsPerSlot per slot: start/stop of each of the three kernels
@@ -166,12 +173,52 @@ int drain_profile(cavmd_workspace* ws)
     return CAVMD_OK;
 }
 
+// A captured evaluation carries a frozen `sequence` argument: from the second replay on the host-visible ready flag
+// already holds that value, so the flag protocol of cavmd_result_read cannot tell a finished replay from a running one.
+// Once a workspace has been captured its results are read behind a device synchronisation instead (include/cavmd.h).
+void note_capture(cavmd_workspace* ws, hipStream_t stream)
+{
+    if (ws->captured)
+        return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        ws->captured = true;
+}
+
+// Where the single-launch evaluation is the default (measured on MI355X, profiles/r02/microbench_persistent_*.txt).
+bool persistent_auto(size_t N)
+{
+    (void)N;
+    return true;
+}
+
 unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_cu)
 {
     size_t tiles = (work_items + tile - 1) / tile;
     size_t cap = (size_t)num_cu * (size_t)blocks_per_cu;
     size_t g = tiles < cap ? tiles : cap;
     return (unsigned)(g ? g : 1);
+}
+
+// The single-launch kernel keeps the charges of a block's tiles in dynamic LDS (up to kPersistMaxLds); HIP wants the
+// ceiling raised per kernel before a launch may ask for more than 64 KiB.
+hipError_t allow_large_lds()
+{
+    // (per device: called from cavmd_create under its device guard)
+    hipError_t once = [] {
+        hipError_t e = hipSuccess;
+#define CAVMD_ALLOW(UNR, NTS)                                                                                    \
+    if (e == hipSuccess)                                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, UNR, NTS>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
+        CAVMD_ALLOW(1, false)
+        CAVMD_ALLOW(1, true)
+        CAVMD_ALLOW(2, false)
+        CAVMD_ALLOW(2, true)
+#undef CAVMD_ALLOW
+        return e;
+    }();
+    return once;
 }
 
 // Per-kernel timing for bench.py's roofline leg.  When profiling is on, every kernel is launched through
@@ -194,16 +241,22 @@ struct LaunchScope
             ev = &ws->events[kEventsPerSlot * ws->pending];
     }
     template <class K, class... Args>
-    int launch(int slot, K kernel, unsigned grid, unsigned block, Args... args)
+    int launch_lds(int slot, size_t lds_bytes, K kernel, unsigned grid, unsigned block, Args... args)
     {
         if (ev)
         {
-            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, ev[2 * slot], ev[2 * slot + 1], 0, args...);
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, ev[2 * slot], ev[2 * slot + 1], 0,
+                                  args...);
             used |= 1u << slot;
         }
         else
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, args...);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, args...);
         return hip_status(hipGetLastError());
+    }
+    template <class K, class... Args>
+    int launch(int slot, K kernel, unsigned grid, unsigned block, Args... args)
+    {
+        return launch_lds(slot, 0, kernel, grid, block, args...);
     }
     void commit()
     {
@@ -274,7 +327,20 @@ int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
     if (e == hipSuccess)
         e = hipMemset(ws->d_result, 0, sizeof(cavmd_result));
     if (e == hipSuccess)
-        e = hipHostMalloc((void**)&ws->h_result, sizeof(HostResult), hipHostMallocMapped);
+        e = hipMalloc((void**)&ws->d_granules, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid);
+    if (e == hipSuccess) // tag 0 = never valid
+        e = hipMemset(ws->d_granules, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&ws->d_epoch, sizeof(unsigned));
+    if (e == hipSuccess)
+    {
+        const unsigned one = 1;
+        e = hipMemcpy(ws->d_epoch, &one, sizeof(one), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess)
+        e = allow_large_lds();
+    if (e == hipSuccess) // coherent: the polled flag must not depend on HIP_HOST_COHERENT
+        e = hipHostMalloc((void**)&ws->h_result, sizeof(HostResult), hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess)
         e = hipHostGetDevicePointer((void**)&ws->h_result_dev, ws->h_result, 0);
     if (e != hipSuccess)
@@ -300,6 +366,10 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipFree(ws->d_ipart);
     if (ws->d_result)
         (void)hipFree(ws->d_result);
+    if (ws->d_granules)
+        (void)hipFree(ws->d_granules);
+    if (ws->d_epoch)
+        (void)hipFree(ws->d_epoch);
     if (ws->h_result)
         (void)hipHostFree(ws->h_result);
     if (ws->d_kvec)
@@ -340,6 +410,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
+    note_capture(ws, stream);
     LaunchScope ls(ws, stream);
     if (ls.status != CAVMD_OK)
         return ls.status;
@@ -374,6 +445,54 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu / 4)
         unroll >>= 1;
     const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
+    v2d* force2 = reinterpret_cast<v2d*>(d_force);
+    // Force stores bypass the caches for all but small N: the array is consumed much later (by the integrator, after
+    // every other force of the step), and not leaving 32 N dirty bytes behind shortens this kernel's drain and spares
+    // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
+    const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
+
+    // ---- ONE launch (cavmd_persistent_kernel.hpp): the same grid and tiles as launch 1 below, so the same partials and
+    // the same fold, bit for bit; possible while the charges of a block's tiles fit in LDS and the whole grid is resident
+    // at once (g1 <= CUs x blocks per CU by construction; LDS and registers admit that many blocks per CU).
+    {
+        const size_t tile = (size_t)kReduceBlock * unroll;
+        const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        const size_t lds = slots * tile * sizeof(double);
+        const bool resident = lds <= kPersistMaxLds && g1 <= kMaxPersistGrid
+                              && (size_t)ws->reduce_blocks_per_cu * (lds + 1024) <= (size_t)160 * 1024
+                              && ws->reduce_blocks_per_cu <= 4;
+        if (resident && (ws->persistent > 0 || (ws->persistent < 0 && persistent_auto(N))))
+        {
+            ws->sequence += 1;
+            const AosInputT<2> inx {in.pos2, in.charge, in.image};
+            const SyncState sync {ws->d_granules, ws->d_epoch};
+#define CAVMD_LAUNCH_PERSIST(UNR, NTS)                                                                               \
+    st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, UNR, NTS>, g1, kPersistBlock, inx, n, Lx, Ly, Lz, \
+                       dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2);
+            if (unroll == 2)
+            {
+                if (nt_store)
+                    CAVMD_LAUNCH_PERSIST(2, true)
+                else
+                    CAVMD_LAUNCH_PERSIST(2, false)
+            }
+            else
+            {
+                if (nt_store)
+                    CAVMD_LAUNCH_PERSIST(1, true)
+                else
+                    CAVMD_LAUNCH_PERSIST(1, false)
+            }
+#undef CAVMD_LAUNCH_PERSIST
+            if (st != CAVMD_OK)
+                return st;
+            ls.commit();
+            ws->last_stream = stream;
+            ws->computed = true;
+            return CAVMD_OK;
+        }
+    }
+
     // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
     // by the force map: keeping it temporal lets the map hit it in the Infinity Cache while 8 N bytes are small
     // (measured -4 % per evaluation at N = 1e6, -3 % at 4e6, 0 at 6e6) but costs +16 % at N = 1e7, where it only
@@ -407,11 +526,6 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
 
     ws->sequence += 1;
     const unsigned g2 = grid_for(2 * N, kMapBlock * kMapUnroll, ws->num_cu, ws->map_blocks_per_cu);
-    v2d* force2 = reinterpret_cast<v2d*>(d_force);
-    // Force stores bypass the caches for all but small N: the array is consumed much later (by the integrator, after
-    // every other force of the step), and not leaving 32 N dirty bytes behind shortens this kernel's drain and spares
-    // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
-    const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
     // Reverse tile order in the force map: the charge lines the reduction touched last are then asked for first.  It only
     // matters where the per-XCD share of the charges (N bytes) is about the size of an XCD's 4 MiB L2: -3.3 % per
     // evaluation at N = 4e6, neutral at 3e5 / 1e6 / 2e6 / 1e7 (scripts/ab_tunable.py map_reverse 0 1 ...).
@@ -493,6 +607,7 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
+    note_capture(ws, stream);
     LaunchScope ls(ws, stream);
     if (ls.status != CAVMD_OK)
         return ls.status;
@@ -559,23 +674,36 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
     if (!ws->computed)
         return CAVMD_ERR_NOT_COMPUTED;
     DeviceGuard guard(ws->device);
-    // The publishing block stores the result block and then a sequence flag (system-scope release) into mapped pinned
-    // host memory.  Spin on that flag: the energies arrive as soon as the prologue of the force map has them, about a
-    // PCIe write after, instead of a stream synchronisation (~15 us).  The stream going idle ends the wait as well
-    // (a graph replay carries a frozen sequence number, and a failed launch never sets the flag).
-    const uint64_t want = ws->sequence;
-    for (;;)
+    if (ws->captured)
     {
-        if (__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE) == want)
-            break;
-        const hipError_t q = hipStreamQuery(ws->last_stream);
-        if (q == hipSuccess)
+        // graph replays: the flag cannot be trusted (frozen sequence) and the replay stream is unknown -> wait for the device
+        CAVMD_HIP_TRY(hipDeviceSynchronize());
+    }
+    else
+    {
+        // The publishing block stores the result block and then a sequence flag (system-scope release) into mapped pinned
+        // host memory.  Spin on that flag: the energies arrive as soon as the block that computes the scalars has them,
+        // about a PCIe write after, instead of a stream synchronisation (~15 us).  The stream going idle ends the wait as
+        // well (a failed launch, or a timed-out single-launch kernel, never sets the flag).
+        const uint64_t want = ws->sequence;
+        for (;;)
         {
-            (void)__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE);
-            break;
+            if (__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE) == want)
+                break;
+            const hipError_t q = hipStreamQuery(ws->last_stream);
+            if (q == hipSuccess)
+            {
+                (void)__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE);
+                break;
+            }
+            if (q != hipErrorNotReady)
+                return (int)q;
         }
-        if (q != hipErrorNotReady)
-            return (int)q;
+    }
+    if (__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
+    {
+        __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
+        return CAVMD_ERR_SYNC_TIMEOUT;
     }
     memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
     return CAVMD_OK;
@@ -854,6 +982,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->small_system_max_n = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "persistent"))
+    {
+        if (value < -1 || value > 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->persistent = value;
+        return CAVMD_OK;
+    }
     return CAVMD_ERR_INVALID_VALUE;
 }
 
@@ -875,6 +1010,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->map_reverse;
     else if (!strcmp(name, "small_system_max_n"))
         *value = ws->small_system_max_n;
+    else if (!strcmp(name, "persistent"))
+        *value = ws->persistent;
     else
         return CAVMD_ERR_INVALID_VALUE;
     return CAVMD_OK;
@@ -912,6 +1049,9 @@ const char* cavmd_error_string(int status)
         return "bad cavity parameters (K == 0 or non-finite)";
     case CAVMD_ERR_NOT_COMPUTED:
         return "no evaluation has been enqueued on this workspace yet";
+    case CAVMD_ERR_SYNC_TIMEOUT:
+        return "the single-launch kernel's inter-workgroup wait timed out (its blocks were not resident together); "
+               "forces of that evaluation are NaN";
     default:
         break;
     }

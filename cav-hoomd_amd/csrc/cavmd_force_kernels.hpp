@@ -387,7 +387,44 @@ __device__ __forceinline__ Scalars reduce_partials_and_finalize(const Input& in,
                 acc.merge(o[j]);           // (a default-constructed Accum is the identity for the ragged last one)
     }
     CAVMD_STAMP(1);
-    acc = block_reduce<BLOCK>(acc);
+    if (BLOCK == 256 && nparts <= 256)
+    {
+        // Two-level fold, the same tree the single-launch kernel walks across workgroups (cavmd_persistent_kernel.hpp):
+        // 16 consecutive partials -> group total (one DPP row each), then the <= 16 group totals.
+        __shared__ double s_gd[16][kNumPartDoubles];
+        __shared__ int s_gi[16][kNumPartInts];
+        acc = row_fold16(acc);
+        CAVMD_STAMP(2);
+        if ((threadIdx.x & 15) == 0)
+        {
+            const int gidx = threadIdx.x >> 4;
+            s_gd[gidx][0] = acc.hx; s_gd[gidx][1] = acc.lx; s_gd[gidx][2] = acc.hy; s_gd[gidx][3] = acc.ly;
+            s_gd[gidx][4] = acc.hz; s_gd[gidx][5] = acc.lz; s_gd[gidx][6] = acc.sx; s_gd[gidx][7] = acc.sy;
+            s_gd[gidx][8] = acc.sz;
+            s_gi[gidx][0] = acc.lmin;
+            s_gi[gidx][1] = acc.lcnt;
+        }
+        __syncthreads();
+        if (threadIdx.x < kWave)
+        {
+            Accum o;
+            if (threadIdx.x < (nparts + 15) / 16)
+            {
+                const int gidx = threadIdx.x;
+                o.hx = s_gd[gidx][0]; o.lx = s_gd[gidx][1]; o.hy = s_gd[gidx][2]; o.ly = s_gd[gidx][3];
+                o.hz = s_gd[gidx][4]; o.lz = s_gd[gidx][5]; o.sx = s_gd[gidx][6]; o.sy = s_gd[gidx][7];
+                o.sz = s_gd[gidx][8];
+                o.lmin = s_gi[gidx][0];
+                o.lcnt = s_gi[gidx][1];
+            }
+            Accum t;
+            t.merge(o);
+            acc = row_fold16(t);
+        }
+        CAVMD_STAMP(3);
+    }
+    else
+        acc = block_reduce<BLOCK>(acc);
     return scalars_from_total<Input>(acc, guess, in, N, Lx, Ly, Lz, prm, want_energies);
 }
 
@@ -421,6 +458,8 @@ struct HostResult
 {
     cavmd_result result;
     uint64_t ready;
+    unsigned sync_error; // raised by the single-launch kernel when its bounded inter-workgroup wait timed out
+    unsigned pad;
 };
 __device__ __forceinline__ void publish_to_host(HostResult* __restrict__ host, const Scalars& sc, unsigned N,
                                                 unsigned nparts, uint64_t sequence)

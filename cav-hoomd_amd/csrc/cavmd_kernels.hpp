@@ -1,6 +1,8 @@
 // cavmd_kernels.hpp -- CDNA4 (gfx950) device code of the cavity-force path (umbrella header).
 //
-// An evaluation is TWO launches, both bandwidth- or latency-bound (no MFMA: ~60 VALU operations per 92 bytes):
+// An evaluation is ONE launch for 2048 < N <~ 5e6 (cavmd_persistent_kernel.hpp: both phases below in one grid of
+// co-resident blocks, charges kept in LDS between them), one single-block launch up to 2048 particles, and otherwise
+// TWO launches, all bandwidth- or latency-bound (no MFMA: ~60 VALU operations per 92 bytes):
 //
 //   dipole_partials_kernel       streams pos (32 B) + charge (8 B) + image (12 B) per particle, unwraps, forms the addends
 //                                c_i * r_i exactly as the reference does (one rounding per operation, no FMA), accumulates
@@ -21,9 +23,10 @@
 // a given (N, launch geometry).  The kernel boundary is the only inter-workgroup hand-off.
 //
 // Files: cavmd_reduce.hpp (double-double arithmetic, DPP, block trees), cavmd_force_kernels.hpp (the force path),
-//        cavmd_observable_kernels.hpp (rows f2-f4 of the scope table).
+//        cavmd_persistent_kernel.hpp (the single-launch evaluation), cavmd_observable_kernels.hpp (rows f2-f4).
 #pragma once
 
 #include "cavmd_reduce.hpp"
 #include "cavmd_force_kernels.hpp"
+#include "cavmd_persistent_kernel.hpp"
 #include "cavmd_observable_kernels.hpp"

@@ -3,28 +3,37 @@
 //   phase 1   every block streams its tiles (pos 32 + charge 8 + image 12 B per particle) exactly as
 //             dipole_partials_kernel does -- same tile assignment, same double-double accumulation, same block tree,
 //             hence the same per-block partial, bit for bit -- and parks the charges it read in LDS.
-//   hand-off  thread 0 of every block publishes the block's partial as 8-byte {tag, 32-bit value} granules; every block
-//             then waits until the granules of ALL blocks carry this evaluation's tag and folds them in the same fixed
-//             order as reduce_partials_and_finalize (thread t: records t, t + BLOCK, ...; then the block tree), so every
-//             block obtains the same bits and no float atomics are involved.  Block 0 publishes cavmd_result.
+//   hand-off  a two-level all-reduce across the (<= 256) workgroups, walking the same fixed tree as the two-launch
+//             path's fold (reduce_partials_and_finalize): thread 0 of every block publishes the block's partial as a
+//             record of 8-byte {tag, 32-bit value} granules; the first block of every group of 16 consecutive blocks
+//             gathers its group's records, folds them (row_fold16) and publishes the group total; every block then
+//             gathers the <= 16 group totals and folds them.  Every block obtains the same bits; no float atomics.
+//             Block 0 publishes cavmd_result.
 //   phase 2   every block writes the forces of its own tiles from the charges in LDS (dense 16-byte chunks): the
 //             charge array is not read a second time (84 instead of 92 bytes per particle cross the memory bus) and the
 //             second launch with its ramp, drain and re-fold prologue disappears.
 //
 // Inter-workgroup protocol (cdna_hip_programming.md, Guideline 16, form R2 "the data is the flag"): each granule is ONE
-// naturally aligned 8-byte relaxed agent-scope atomic (global_store/load_dwordx2 sc0 sc1), carries its own tag and is
+// naturally aligned 8-byte relaxed agent-scope atomic (global_store/load_dwordx2 sc1), carries its own tag and is
 // validated individually by the reader, so no release/acquire ordering between granules, no separate flag, no fence and
 // no dependence on dispatch order, timing or XCD placement are needed -- only that all blocks of the grid are resident
-// together (grid <= CUs x blocks per CU, checked on the host against the occupancy query).  The tag is the epoch word of
-// the workspace, read from DEVICE memory at kernel start and advanced by block 0 once its wait has succeeded (every
-// block has published by then, so every block has read it): a captured launch replays correctly, nothing needs zeroing
-// between launches.  Every spin is bounded: on a time-out the block raises the sync_error word of the host-visible result
-// block and fills its share of the force array with NaN, then exits like the others.
+// together (grid <= CUs, one block per CU fits by construction).  Why two levels: a flat all-gather (every block reads
+// every record) makes up to 1024 waves spin on the same 320 lines of the memory side -- measured 4.6 us per hand-off at
+// N = 1e6 whichever way the waiting was organised (profiles/r02/microbench_persistent_flat_*.txt); here a waiting block
+// polls 20 lines, from ONE wave.  The tag is the epoch word of the workspace, read from DEVICE memory at kernel start and
+// advanced by block 0 once it holds the total (every block has published by then, so every block has read it): a
+// captured launch replays correctly, nothing needs zeroing between launches.  Every spin is bounded: on a time-out the
+// block raises the sync_error word of the host-visible result block and fills its share of the force array with NaN.
 #pragma once
 
 #include "cavmd_force_kernels.hpp"
 
 #pragma clang fp contract(off)
+
+// Diagnostic hook (csrc/microbench.hip): per-block time stamps at numbered points of the kernel; nothing in the product.
+#ifndef CAVMD_PSTAMP
+#define CAVMD_PSTAMP(k)
+#endif
 
 namespace cavmd
 {
@@ -32,82 +41,107 @@ namespace cavmd
 constexpr int kGranulesPerRecord = 2 * kNumPartDoubles + kNumPartInts; // 9 doubles as 18 halves + lmin + lcnt
 constexpr unsigned kSpinLimit = 4000000;                               // ~ seconds; a healthy wait is microseconds
 
+constexpr int kGroup = 16;           // blocks per first-level group = lanes of a DPP row
+constexpr unsigned kMaxPersistGrid = kGroup * kGroup;
+constexpr unsigned kGroupCopies = 8; // the group totals are published in 8 copies; block b polls copy b % 8, so a line of
+                                     // group records has 32 pollers instead of 256 (a one-to-255 broadcast through one
+                                     // line costs ~1 us more than through lines with 32 pollers: scripts/dev/pingpong.hip)
+
 struct SyncState
 {
-    unsigned long long* granules; // [kGranulesPerRecord][stride] {tag << 32 | value}
+    unsigned long long* granules; // kMaxPersistGrid block records, then kGroupCopies x kGroup group records; a record is
+                                  // kGranulesPerRecord granules {tag << 32 | value} = 160 contiguous bytes
     unsigned* epoch;              // tag of the next evaluation (never 0)
-    unsigned stride;
 };
 
-__device__ __forceinline__ void granule_store(unsigned long long* g, unsigned tag, unsigned value)
-{
-    __hip_atomic_store(g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long* g)
 {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// thread 0 of a block: its block total -> granules of record `b`
-__device__ __forceinline__ void publish_record(const SyncState& st, unsigned b, unsigned tag, const Accum& a)
+// Wave 0 (all 64 lanes active): the Accum held by lane 0 -> record `rec` of `copies` consecutive copies of a slab of
+// `slab_records` records.  The 20 words are broadcast through SGPRs; one wave instruction stores three copies (60 lanes,
+// 160 contiguous bytes per copy).  Twenty separate 8-byte write-through stores from a single lane leave the CU one after
+// the other -- the guide's Pitfall 7 in miniature.
+__device__ __forceinline__ void publish_record(unsigned long long* slab, unsigned slab_records, unsigned copies, unsigned rec,
+                                               unsigned tag, const Accum& a)
 {
     const double d[kNumPartDoubles] = {a.hx, a.lx, a.hy, a.ly, a.hz, a.lz, a.sx, a.sy, a.sz};
-    unsigned long long* g = st.granules + b;
+    const unsigned lane = threadIdx.x;
+    const unsigned field = lane % kGranulesPerRecord, copy0 = lane / kGranulesPerRecord; // copy0 = 0, 1, 2 (3: idle lanes)
+    unsigned mine = 0;
 #pragma unroll
     for (int i = 0; i < kNumPartDoubles; ++i)
     {
-        granule_store(g + (size_t)(2 * i) * st.stride, tag, (unsigned)__double2loint(d[i]));
-        granule_store(g + (size_t)(2 * i + 1) * st.stride, tag, (unsigned)__double2hiint(d[i]));
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(d[i]));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(d[i]));
+        mine = field == 2u * i ? lo : mine;
+        mine = field == 2u * i + 1u ? hi : mine;
     }
-    granule_store(g + (size_t)(2 * kNumPartDoubles) * st.stride, tag, (unsigned)a.lmin);
-    granule_store(g + (size_t)(2 * kNumPartDoubles + 1) * st.stride, tag, (unsigned)a.lcnt);
+    const unsigned lmin = (unsigned)__builtin_amdgcn_readfirstlane(a.lmin);
+    const unsigned lcnt = (unsigned)__builtin_amdgcn_readfirstlane(a.lcnt);
+    mine = field == 2u * kNumPartDoubles ? lmin : mine;
+    mine = field == 2u * kNumPartDoubles + 1u ? lcnt : mine;
+    const unsigned long long granule = ((unsigned long long)tag << 32) | mine;
+    for (unsigned c = copy0; c < copies && copy0 < 3; c += 3)
+        __hip_atomic_store(slab + ((size_t)c * slab_records + rec) * kGranulesPerRecord + field, granule, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wait until record `r` carries `tag` in every granule, then return it.  POLL_ONE: spin on the granule that was stored
-// last and fetch the other 19 only once it shows the tag (all 20 are validated either way).  Returns false on time-out.
-template <bool POLL_ONE>
-__device__ __forceinline__ bool wait_record(const SyncState& st, unsigned r, unsigned tag, Accum& o)
+// Wave 0 (all 64 lanes active): wait until records first .. first + count - 1 (count <= 16, contiguous in the slab) carry
+// `tag` in every granule, then hand record first + l to lane l (identity Accum for l >= count).  A round is 5 coalesced
+// wave loads (count * 160 bytes <= 20 lines); every granule is validated by its own tag; the words reach their lanes
+// through a 1280-byte LDS transpose that only this wave touches.  Returns false on time-out (wave-uniform).
+__device__ __forceinline__ bool gather_records(const unsigned long long* slab, unsigned first, unsigned count, unsigned tag,
+                                               unsigned* s_words, Accum& o)
 {
-    const unsigned long long* g = st.granules + r;
-    unsigned v[kGranulesPerRecord];
-    unsigned spins = 0;
-    for (;;)
+    constexpr int ROUNDS = (kGroup * kGranulesPerRecord + kWave - 1) / kWave; // 5
+    const unsigned lane = threadIdx.x;
+    const unsigned total = count * kGranulesPerRecord;
+    const unsigned long long* g = slab + (size_t)first * kGranulesPerRecord;
+    unsigned long long x[ROUNDS];
+    for (unsigned spins = 0;; ++spins)
     {
-        bool ok = true;
-        if (POLL_ONE)
-        {
-            const unsigned long long x = granule_load(g + (size_t)(kGranulesPerRecord - 1) * st.stride);
-            ok = (unsigned)(x >> 32) == tag;
-        }
-        if (ok)
-        {
+        // all five loads in flight together (clamped index instead of a branch per load: hipcc otherwise waits for each
+        // load before it issues the next, five round trips per round)
 #pragma unroll
-            for (int k = 0; k < kGranulesPerRecord; ++k)
-            {
-                const unsigned long long x = granule_load(g + (size_t)k * st.stride);
-                v[k] = (unsigned)x;
-                ok = ok && ((unsigned)(x >> 32) == tag);
-            }
+        for (int j = 0; j < ROUNDS; ++j)
+        {
+            const unsigned i = j * kWave + lane;
+            x[j] = granule_load(g + (i < total ? i : total - 1));
         }
-        if (ok)
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j)
+            ok = ok && ((unsigned)(x[j] >> 32) == tag);
+        if (__all(ok))
             break;
-        if (++spins > kSpinLimit)
+        if (spins > kSpinLimit)
             return false;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
     }
-    o.hx = __hiloint2double((int)v[1], (int)v[0]);   o.lx = __hiloint2double((int)v[3], (int)v[2]);
-    o.hy = __hiloint2double((int)v[5], (int)v[4]);   o.ly = __hiloint2double((int)v[7], (int)v[6]);
-    o.hz = __hiloint2double((int)v[9], (int)v[8]);   o.lz = __hiloint2double((int)v[11], (int)v[10]);
-    o.sx = __hiloint2double((int)v[13], (int)v[12]); o.sy = __hiloint2double((int)v[15], (int)v[14]);
-    o.sz = __hiloint2double((int)v[17], (int)v[16]);
-    o.lmin = (int)v[18];
-    o.lcnt = (int)v[19];
+#pragma unroll
+    for (int j = 0; j < ROUNDS; ++j)
+        if ((unsigned)(j * kWave) + lane < total)
+            s_words[j * kWave + lane] = (unsigned)x[j];
+    // same wave: LDS operations complete in order, no barrier needed
+    if (lane < count)
+    {
+        const unsigned* w = s_words + lane * kGranulesPerRecord;
+        o.hx = __hiloint2double((int)w[1], (int)w[0]);   o.lx = __hiloint2double((int)w[3], (int)w[2]);
+        o.hy = __hiloint2double((int)w[5], (int)w[4]);   o.ly = __hiloint2double((int)w[7], (int)w[6]);
+        o.hz = __hiloint2double((int)w[9], (int)w[8]);   o.lz = __hiloint2double((int)w[11], (int)w[10]);
+        o.sx = __hiloint2double((int)w[13], (int)w[12]); o.sy = __hiloint2double((int)w[15], (int)w[14]);
+        o.sz = __hiloint2double((int)w[17], (int)w[16]);
+        o.lmin = (int)w[18];
+        o.lcnt = (int)w[19];
+    }
     return true;
 }
 
 extern __shared__ __attribute__((aligned(16))) double s_dyn_charge[];
 
-template <int BLOCK, int UNROLL, bool NT_STORE, bool POLL_ONE>
+template <int BLOCK, int UNROLL, bool NT_STORE>
 __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> in, unsigned N, double Lx, double Ly, double Lz,
                                                                   DeviceParams prm, int L_typeid, SyncState st,
                                                                   uint64_t sequence, cavmd_result* __restrict__ res,
@@ -121,6 +155,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     double* s_charge = s_dyn_charge;
     const unsigned G = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
 
+    CAVMD_PSTAMP(0);
     // this evaluation's tag, and the speculative photon row (the driver appends the photon last)
     const unsigned tag = __hip_atomic_load(st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
@@ -161,26 +196,43 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             s_charge[slot * TILE + u * BLOCK + tid] = c;
         }
     }
+    CAVMD_PSTAMP(1);
     acc = block_reduce<BLOCK>(acc);
+    CAVMD_PSTAMP(2);
 
-    // ---- hand-off: publish this block's partial, gather everybody's, fold in the fixed order -----------------------------
-    if (tid == 0)
-        publish_record(st, b, tag, acc);
+    // ---- hand-off: two-level all-reduce across the workgroups (wave 0; the other waves wait at the barrier below) ---------
+    __shared__ int s_failed;
+    __shared__ unsigned s_words[kGroup * kGranulesPerRecord];
+    unsigned long long* const block_slab = st.granules;
+    unsigned long long* const group_slab = st.granules + (size_t)kMaxPersistGrid * kGranulesPerRecord;
     Accum tot;
-    bool failed = false;
-    for (unsigned r = tid; r < G; r += BLOCK)
+    if (tid < kWave)
     {
-        Accum o;
-        if (!wait_record<POLL_ONE>(st, r, tag, o))
+        bool ok = true;
+        publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc);
+        if ((b & (kGroup - 1)) == 0)
         {
-            failed = true;
-            break;
+            // first block of group b / 16: gather the group's records, fold, publish the group total
+            Accum o, t;
+            ok = gather_records(block_slab, b, min(G - b, (unsigned)kGroup), tag, s_words, o);
+            t.merge(o);
+            t = row_fold16(t);
+            publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t);
         }
-        tot.merge(o);
+        CAVMD_PSTAMP(7);
+        Accum o, t;
+        ok = gather_records(group_slab + (size_t)(b % kGroupCopies) * kGroup * kGranulesPerRecord, 0, (G + kGroup - 1) / kGroup,
+                            tag, s_words, o)
+             && ok;
+        t.merge(o);
+        tot = row_fold16(t);
+        if (tid == 0)
+            s_failed = !ok;
     }
-    // (the barrier also separates the two uses of the block tree's LDS arrays)
-    const bool any_failed = __syncthreads_or(failed);
-    tot = block_reduce<BLOCK>(tot);
+    CAVMD_PSTAMP(3);
+    __syncthreads();
+    const bool any_failed = s_failed;
+    CAVMD_PSTAMP(4);
     const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, b == 0);
     if (tid == 0)
     {
@@ -202,6 +254,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         }
     }
     __syncthreads();
+    CAVMD_PSTAMP(5);
     MapScalars m;
     m.Dqx = s_m[0]; m.Dqy = s_m[1]; m.Fx = s_m[2]; m.Fy = s_m[3]; m.Fz = s_m[4];
     m.photon = s_mi[0];
@@ -286,6 +339,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             }
         }
     }
+    CAVMD_PSTAMP(6);
 }
 
 } // namespace cavmd

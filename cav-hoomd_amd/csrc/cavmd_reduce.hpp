@@ -311,6 +311,43 @@ __device__ __forceinline__ Accum block_reduce_256(Accum a)
     return a;
 }
 
+// Fold of the 16 lanes of one DPP row (lanes 16 r .. 16 r + 15 of a wave) in a fixed order: the recursive halving of
+// block_reduce_256 stopped at the row (5 double-double merges).  The total is valid in every lane with (lane & 3) == 0,
+// in particular in the row's first lane.  All 64 lanes of the wave must be active (DPP reads neighbours).
+// Used for the two-level fold of the per-block partials: 16 consecutive partials -> group total -> total of <= 16 groups,
+// by the fused force map (all in one block) and by the single-launch kernel (group leaders, then every block).
+__device__ __forceinline__ Accum row_fold16(Accum a)
+{
+    if (__any(a.lcnt != 0))
+    {
+#define CAVMD_L_STEP(CTRL)                                          \
+    a.sx += dpp_f64<CTRL, 0xF>(a.sx, 0.0);                          \
+    a.sy += dpp_f64<CTRL, 0xF>(a.sy, 0.0);                          \
+    a.sz += dpp_f64<CTRL, 0xF>(a.sz, 0.0);                          \
+    a.lmin = min(a.lmin, dpp_i32<CTRL, 0xF>(a.lmin, INT_MAX));      \
+    a.lcnt += dpp_i32<CTRL, 0xF>(a.lcnt, 0);
+        CAVMD_L_STEP(0xB1)  // quad_perm [1,0,3,2]
+        CAVMD_L_STEP(0x4E)  // quad_perm [2,3,0,1]
+        CAVMD_L_STEP(0x141) // row_half_mirror
+        CAVMD_L_STEP(0x140) // row_mirror: every lane of the row holds the row's L totals
+#undef CAVMD_L_STEP
+    }
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const DD X {a.hx, a.lx}, Y {a.hy, a.ly}, Z {a.hz, a.lz}, W {0.0, 0.0};
+    const DD P = dd_sum(dd_sel(b0, Z, X), dd_dpp<0xB1>(dd_sel(b0, X, Z)));
+    const DD Q = dd_sum(dd_sel(b0, W, Y), dd_dpp<0xB1>(dd_sel(b0, Y, W)));
+    DD R = dd_sum(dd_sel(b1, Q, P), dd_dpp<0x4E>(dd_sel(b1, P, Q)));
+    R = dd_sum(R, dd_dpp<0x124>(R)); // row_ror:4
+    R = dd_sum(R, dd_dpp<0x128>(R)); // row_ror:8 -> lane&3 = 0: x, 1: z, 2: y totals of the row
+    const DD Tz = dd_dpp<0x55>(R);   // quad_perm [1,1,1,1]
+    const DD Ty = dd_dpp<0xAA>(R);   // quad_perm [2,2,2,2]
+    a.hx = R.hi; a.lx = R.lo;
+    a.hy = Ty.hi; a.ly = Ty.lo;
+    a.hz = Tz.hi; a.lz = Tz.lo;
+    return a;
+}
+
 template <int BLOCK>
 __device__ __forceinline__ Accum block_reduce(Accum a)
 {

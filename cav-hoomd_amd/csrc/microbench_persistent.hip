@@ -1,0 +1,216 @@
+// microbench_persistent.hip -- developer tool (not part of the product or of bench.py): the single-launch evaluation
+// (cavmd_persistent_kernel.hpp) against the two-launch path, interleaved round by round on HBM-cold frames, plus a
+// per-block time line of the single-launch kernel (wall_clock64 stamps, 10 ns resolution).
+//
+//   ./microbench_persistent [N=1000001] [frames=7] [rounds=9] [launches_per_round=20]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "cavmd.h"
+
+constexpr int kStampSlots = 8;
+__device__ unsigned long long g_pstamps[4096 * kStampSlots];
+#define CAVMD_PSTAMP(k)                                                \
+    do                                                                 \
+    {                                                                  \
+        if (threadIdx.x == 0)                                          \
+            g_pstamps[blockIdx.x * kStampSlots + (k)] = wall_clock64(); \
+    } while (0)
+#include "cavmd_kernels.hpp"
+
+using namespace cavmd;
+
+#define CHECK(x)                                                                          \
+    do                                                                                    \
+    {                                                                                     \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess)                                                             \
+        {                                                                                 \
+            fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                      \
+        }                                                                                 \
+    } while (0)
+
+struct Variant
+{
+    std::string name;
+    std::function<void(int frame)> launch;
+    std::vector<double> us;
+};
+
+int main(int argc, char** argv)
+{
+    const size_t N = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000001;
+    const int frames = argc > 2 ? atoi(argv[2]) : 7;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 9;
+    const int per_round = argc > 4 ? atoi(argv[4]) : 20;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int CU = prop.multiProcessorCount;
+    printf("device %s, %d CUs; N=%zu frames=%d rounds=%d launches/round=%d\n", prop.gcnArchName, CU, N, frames, rounds,
+           per_round);
+
+    std::mt19937_64 rng(1234);
+    std::uniform_real_distribution<double> U(-100.0, 100.0), C(-1.0, 1.0);
+    std::vector<cavmd_double4> h_pos(N);
+    std::vector<double> h_chg(N);
+    std::vector<cavmd_int3> h_img(N);
+    for (size_t i = 0; i < N; ++i)
+    {
+        h_pos[i].x = U(rng); h_pos[i].y = U(rng); h_pos[i].z = U(rng);
+        uint64_t tag = (i == N - 1) ? 2 : (i & 1);
+        memcpy(&h_pos[i].w, &tag, 8);
+        h_chg[i] = (i == N - 1) ? 0.0 : C(rng);
+        h_img[i].x = (int)(rng() % 5) - 2; h_img[i].y = (int)(rng() % 5) - 2; h_img[i].z = (int)(rng() % 5) - 2;
+    }
+    std::vector<cavmd_double4*> d_pos(frames), d_frc(frames);
+    std::vector<double*> d_chg(frames);
+    std::vector<cavmd_int3*> d_img(frames);
+    for (int f = 0; f < frames; ++f)
+    {
+        CHECK(hipMalloc((void**)&d_pos[f], N * 32)); CHECK(hipMalloc((void**)&d_frc[f], N * 32));
+        CHECK(hipMalloc((void**)&d_chg[f], N * 8));  CHECK(hipMalloc((void**)&d_img[f], N * 12));
+        CHECK(hipMemcpy(d_pos[f], h_pos.data(), N * 32, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_chg[f], h_chg.data(), N * 8, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_img[f], h_img.data(), N * 12, hipMemcpyHostToDevice));
+    }
+    const unsigned max_parts = CU * 16;
+    double* d_part; int* d_ipart; cavmd_result* d_res; HostResult* d_hres;
+    unsigned long long* d_gran; unsigned* d_epoch;
+    CHECK(hipMalloc((void**)&d_part, sizeof(double) * kNumPartDoubles * max_parts));
+    CHECK(hipMalloc((void**)&d_ipart, sizeof(int) * kNumPartInts * max_parts));
+    CHECK(hipMalloc((void**)&d_res, sizeof(cavmd_result)));
+    CHECK(hipMalloc((void**)&d_hres, sizeof(HostResult)));
+    CHECK(hipMalloc((void**)&d_gran, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
+    CHECK(hipMemset(d_gran, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
+    CHECK(hipMalloc((void**)&d_epoch, 4));
+    const unsigned one = 1;
+    CHECK(hipMemcpy(d_epoch, &one, 4, hipMemcpyHostToDevice));
+    Partials part {d_part, d_ipart, max_parts};
+    SyncState sync {d_gran, d_epoch};
+    const double L = 215.4;
+    const unsigned n = (unsigned)N;
+    hipStream_t st = 0;
+    DeviceParams P; P.g = 1e-3; P.K = 0.0091 * 0.0091; P.gK = P.g / P.K; P.g2K = P.g * P.g / P.K;
+
+    auto in0 = [&](int f) { AosInput in; in.pos2 = (const v2d*)d_pos[f]; in.charge = d_chg[f]; in.image = (const int*)d_img[f]; return in; };
+    auto in1 = [&](int f) { AosInputT<1> in; in.pos2 = (const v2d*)d_pos[f]; in.charge = d_chg[f]; in.image = (const int*)d_img[f]; return in; };
+    auto in2 = [&](int f) { AosInputT<2> in; in.pos2 = (const v2d*)d_pos[f]; in.charge = d_chg[f]; in.image = (const int*)d_img[f]; return in; };
+    auto grid = [&](size_t items, unsigned tile, int bpc) {
+        size_t tiles = (items + tile - 1) / tile; size_t cap = (size_t)CU * bpc; return (unsigned)std::max<size_t>(1, std::min(tiles, cap)); };
+
+    int unroll = 2;
+    while (unroll > 1 && N / ((size_t)256 * unroll) < (size_t)CU / 4)
+        unroll >>= 1;
+    const bool nts = N >= 200000;
+#define ALLOW(UNR, NTS) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+    ALLOW(1, false); ALLOW(1, true); ALLOW(2, false); ALLOW(2, true);
+
+    std::vector<Variant> V;
+    // the product's two-launch sequence
+    V.push_back({"two launches (K1 nt1 bpc1 | fused map u4 bpc2)", [&](int f) {
+                     const unsigned g1 = grid(N, 256 * unroll, 1);
+                     if (unroll == 2)
+                         hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, 256, 2, false>), dim3(g1), dim3(256), 0, st, in1(f), n, L, L, L, 2, part);
+                     else
+                         hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, 256, 1, false>), dim3(g1), dim3(256), 0, st, in1(f), n, L, L, L, 2, part);
+                     const unsigned g2 = grid(2 * N, 1024, 2);
+                     if (nts)
+                         hipLaunchKernelGGL((force_map_aos_fused_kernel<256, 4, true>), dim3(g2), dim3(256), 0, st, in0(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f], false);
+                     else
+                         hipLaunchKernelGGL((force_map_aos_fused_kernel<256, 4, false>), dim3(g2), dim3(256), 0, st, in0(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f], false);
+                 }, {}});
+    auto persist = [&](int f, int bpc) {
+        const unsigned g1 = grid(N, 256 * unroll, bpc);
+        const size_t tile = 256 * unroll;
+        const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        const size_t lds = slots * tile * 8;
+        if (lds > 156 * 1024) { fprintf(stderr, "LDS %zu too large\n", lds); exit(1); }
+#define PL(UNR, NTS) hipLaunchKernelGGL((cavity_persistent_kernel<256, UNR, NTS>), dim3(g1), dim3(256), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f])
+        if (unroll == 2) { if (nts) PL(2, true); else PL(2, false); }
+        else { if (nts) PL(1, true); else PL(1, false); }
+    };
+    V.push_back({"single launch (two-level in-launch all-reduce)", [&](int f) { persist(f, 1); }, {}});
+
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    int frame = 0;
+    for (auto& v : V) for (int f = 0; f < frames; ++f) v.launch(f);
+    CHECK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r)
+    {
+        for (auto& v : V)
+        {
+            CHECK(hipEventRecord(e0, st));
+            for (int k = 0; k < per_round; ++k) { v.launch(frame); frame = (frame + 1) % frames; }
+            CHECK(hipEventRecord(e1, st));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            v.us.push_back(1e3 * ms / per_round);
+        }
+    }
+    CHECK(hipGetLastError());
+    printf("%-52s %10s %10s %12s\n", "variant", "med us", "min us", "evals/s(med)");
+    for (auto& v : V)
+    {
+        std::sort(v.us.begin(), v.us.end());
+        const double med = v.us[v.us.size() / 2], mn = v.us.front();
+        printf("%-52s %10.2f %10.2f %12.0f\n", v.name.c_str(), med, mn, 1e6 / med);
+    }
+
+    // ---- time line of the single-launch kernel: per-block stamps, relative to the first block's start ----------------------
+    for (int mode = 0; mode < 1; ++mode)
+    {
+        const unsigned g1 = grid(N, 256 * unroll, 1);
+        const char* names[8] = {"start", "phase1 done", "block tree done", "total in wave 0", "barrier passed",
+                                "scalars broadcast", "stores issued", "group level done"};
+        std::vector<std::vector<double>> med(8), mx(8), mnv(8);
+        for (int rep = 0; rep < 30; ++rep)
+        {
+            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1); // steady state: the stamps are those of the last launch
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(4096 * kStampSlots);
+            CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
+            unsigned long long t0 = ~0ull;
+            for (unsigned b = 0; b < g1; ++b) t0 = std::min(t0, h[b * kStampSlots]);
+            if (rep == 29)
+            {
+                printf("  per blockIdx%%8 group (start / tree done / fold done, us): ");
+                for (unsigned x = 0; x < 8; ++x)
+                {
+                    double a = 1e9, c = 0, d = 0; unsigned cnt = 0;
+                    for (unsigned b = x; b < g1; b += 8) { a = std::min(a, (double)(h[b * kStampSlots] - t0) * 0.01); c = std::max(c, (double)(h[b * kStampSlots + 2] - t0) * 0.01); d += (double)(h[b * kStampSlots + 4] - t0) * 0.01; ++cnt; }
+                    printf("[%u: %.2f %.2f %.2f] ", x, a, c, d / cnt);
+                }
+                printf("\n  blocks 0..15 start: ");
+                for (unsigned b = 0; b < 16 && b < g1; ++b) printf("%.2f ", (double)(h[b * kStampSlots] - t0) * 0.01);
+                printf("\n  blocks 0..15 fold done: ");
+                for (unsigned b = 0; b < 16 && b < g1; ++b) printf("%.2f ", (double)(h[b * kStampSlots + 4] - t0) * 0.01);
+                printf("\n");
+            }
+            for (int k = 0; k < 8; ++k)
+            {
+                std::vector<double> v(g1);
+                for (unsigned b = 0; b < g1; ++b) v[b] = (double)(h[b * kStampSlots + k] - t0) * 0.01; // 100 MHz -> us
+                std::sort(v.begin(), v.end());
+                med[k].push_back(v[g1 / 2]); mx[k].push_back(v.back()); mnv[k].push_back(v.front());
+            }
+        }
+        printf("time line, single launch, grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
+               g1);
+        for (int k : {0, 1, 2, 7, 3, 4, 5, 6})
+        {
+            std::sort(med[k].begin(), med[k].end()); std::sort(mx[k].begin(), mx[k].end()); std::sort(mnv[k].begin(), mnv[k].end());
+            printf("  %-22s min %6.2f  median %6.2f  max %6.2f\n", names[k], mnv[k][15], med[k][15], mx[k][15]);
+        }
+    }
+    return 0;
+}

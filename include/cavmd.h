@@ -27,7 +27,10 @@
  *     tensor, ...).  The library owns only its workspace.  No allocation, no host synchronisation
  *     and no host<->device copy happens inside cavmd_compute_*; they only enqueue kernels on
  *     `stream` (NULL = the null stream, which is what HOOMD-blue 4.x uses), so a caller may
- *     capture them into a hipGraph.
+ *     capture them into a hipGraph.  One workspace serves one stream at a time (one force object, as in
+ *     the reference).  A workspace that has been captured reads its results (cavmd_result_read,
+ *     cavmd_energies) behind a hipDeviceSynchronize instead of the host-visible flag: a replayed kernel
+ *     carries the sequence number of its capture, so the flag cannot tell replays apart.
  *   - Scalar = double (HOOMD's default HOOMD_LONGREAL_SIZE=64 build).
  *
  * Semantic contract (what "the same result as the reference" means here; file:line = reference)
@@ -61,7 +64,7 @@ extern "C" {
 #endif
 
 #define CAVMD_VERSION_MAJOR 0
-#define CAVMD_VERSION_MINOR 1
+#define CAVMD_VERSION_MINOR 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 #define CAVMD_OK 0
@@ -71,6 +74,9 @@ extern "C" {
 #define CAVMD_ERR_CAPACITY (-3)      /* N exceeds the capacity the workspace was created for */
 #define CAVMD_ERR_BAD_PARAMS (-4)    /* K == 0 or non-finite parameters */
 #define CAVMD_ERR_NOT_COMPUTED (-5)  /* results requested before any cavmd_compute_* call */
+#define CAVMD_ERR_SYNC_TIMEOUT (-6)  /* the single-launch kernel's bounded inter-workgroup wait gave up (its blocks were
+                                        not resident together, e.g. CUs held by a never-ending foreign kernel); that
+                                        evaluation's forces are NaN.  Returned by cavmd_result_read / cavmd_energies. */
 
 /* ---- layouts (bit-compatible with HOOMD-blue's Scalar4 / int3 in a double-precision build) -- */
 typedef struct cavmd_double4
@@ -232,6 +238,9 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
  *   "map_reverse"          -1..1   -1 auto by N, 1: the force map walks its tiles last-to-first, 0: first-to-last
  *   "small_system_max_n"   0..2^20 at or below this N one single-block launch does the whole evaluation (0 = never)
+ *   "persistent"           -1..1   ONE launch per evaluation (reduction, in-launch gather of the partials, force map from
+ *                                  charges kept in LDS): 1 whenever a block's charges fit in LDS (N <~ 5e6), 0 never,
+ *                                  -1 auto (where it measured faster).  Same partials, same fold, same bits as two launches.
  * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value.  None of them changes results
  * beyond the last bit of the dipole (different but fixed summation trees). */
 CAVMD_API int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value);

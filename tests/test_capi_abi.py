@@ -57,7 +57,7 @@ def test_make_params_matches_oracle(capi, ref):
 
 def test_version_and_error_strings(capi):
     lib = capi.load()
-    assert lib.cavmd_version() == 1
+    assert lib.cavmd_version() == 2
     assert "success" in capi.error_string(0)
     assert "no CPU fallback" in capi.error_string(capi.CAVMD_ERR_NO_DEVICE)
     assert capi.error_string(-99) == "unknown cavmd status"

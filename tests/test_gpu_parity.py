@@ -373,7 +373,9 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
     for tun in ({"reduce_blocks_per_cu": 1}, {"reduce_blocks_per_cu": 16}, {"map_blocks_per_cu": 1},
                 {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"map_nt_store": 0}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
                 {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"small_system_max_n": 1 << 20}, {"map_reverse": 1}, {"map_reverse": 0, "map_blocks_per_cu": 1},
-                {"map_reverse": 1, "map_blocks_per_cu": 7}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1}):
+                {"map_reverse": 1, "map_blocks_per_cu": 7}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1},
+                {"persistent": 0}, {"persistent": 1, "reduce_blocks_per_cu": 2},
+                {"persistent": 1, "reduce_blocks_per_cu": 4, "map_nt_store": 0}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
         assert np.all(np.abs(out["dipole"] - base["dipole"]) <= np.spacing(np.abs(base["dipole"])))
@@ -600,3 +602,108 @@ def test_cavity_force_object_end_to_end(ref, oracle_mod):
     assert f.coupling_energy == pytest.approx(2 * refout["energies"][1], rel=1e-10)
     f.detach()
     assert f.energy == 0.0
+
+
+# ---- the single-launch evaluation (cavmd_persistent_kernel.hpp) ----------------------------------------------------------------
+@pytest.mark.parametrize("n", [2049, 3000, 10_000, 65_537, 131_073, 262_145, 1_000_001, 3_000_017])
+def test_single_launch_gives_the_bits_of_two_launches(n):
+    """Same grid, same tiles, same fold order: the one-launch kernel must reproduce the two-launch path bit for bit
+    (forces, dipole high and low words, energies, photon)."""
+    for photon_at in sorted({0, n // 3, n - 1}):
+        cfg = _random_cfg(n, seed=n + photon_at, photon_at=photon_at)
+        two = gpu_eval(cfg, {"persistent": 0})
+        for tun in ({"persistent": 1},):
+            one = gpu_eval(cfg, tun)
+            assert one["result"].n_partials == two["result"].n_partials
+            assert np.array_equal(one["force"], two["force"])
+            assert np.array_equal(one["dipole"], two["dipole"]) and np.array_equal(one["dipole_lo"], two["dipole_lo"])
+            assert np.array_equal(one["energies"], two["energies"]) and one["photon_idx"] == two["photon_idx"] == photon_at
+            assert np.array_equal(np.array(one["result"].total_dipole[:]), np.array(two["result"].total_dipole[:]))
+
+
+def test_single_launch_degenerate_inputs(ref, oracle_mod):
+    # no photon -> zeros; several L-typed particles -> the slow path that reads the type tags
+    cfg = _random_cfg(50_000, seed=5)
+    out = gpu_eval(cfg, {"persistent": 1})
+    assert out["photon_idx"] == -1 and not out["force"].any() and not out["energies"].any()
+    cfg = _random_cfg(50_000, seed=9, photon_at=100)
+    for extra in (99, 101, 25_000, 49_999):
+        cfg["typeid"][extra] = 2
+    one, two = gpu_eval(cfg, {"persistent": 1}), gpu_eval(cfg, {"persistent": 0})
+    assert one["photon_idx"] == 99 and one["n_L"] == 5
+    assert np.array_equal(one["force"], two["force"]) and np.array_equal(one["dipole"], two["dipole"])
+    refout = ref_eval(ref, oracle_mod, cfg)
+    S = force_scales(cfg, refout)
+    assert np.all(np.abs(one["force"][:, :3] - refout["force"][:, :3]) <= 1e-10 * S[:, None] + 1e-300)
+
+
+def test_single_launch_hand_off_under_load_and_reuse():
+    """The in-launch gather, hammered: 3000 evaluations through ONE workspace on data that changes every step (a stale
+    or torn granule from an earlier evaluation would change bits), with a second stream keeping the memory system busy
+    half of the time (uneven load), every result compared bit for bit with the two-launch path on the same frame."""
+    n = 300_001
+    frames = 6
+    cfgs = [_random_cfg(n, seed=900 + f, photon_at=n - 1) for f in range(frames)]
+    dev = "cuda"
+    pos = [torch.from_numpy(np.concatenate([c["position"], cavitymd.state.type_tag_as_double(c["typeid"])[:, None]], axis=1)).to(dev) for c in cfgs]
+    chg = [torch.from_numpy(c["charge"]).to(dev) for c in cfgs]
+    img = [torch.from_numpy(c["image"]).to(dev) for c in cfgs]
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    L = cfgs[0]["box"]
+    want_f, want_d = [], []
+    ws2 = _capi.Workspace(n)
+    ws2.set_tunable("persistent", 0)
+    frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    for f in range(frames):
+        ws2.compute_hoomd(0, n, pos[f].data_ptr(), chg[f].data_ptr(), img[f].data_ptr(), L, 2, prm, frc.data_ptr())
+        torch.cuda.synchronize()
+        want_f.append(frc.clone())
+        want_d.append(np.array(ws2.result().dipole[:]))
+    ws1 = _capi.Workspace(n)
+    ws1.set_tunable("persistent", 1)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 * 2**20, dtype=torch.float32, device=dev)
+    out = [torch.empty((n, 4), dtype=torch.float64, device=dev) for _ in range(frames)]
+    bad = 0
+    for it in range(3000):
+        f = (it * 5 + it // 7) % frames
+        if (it // 50) % 2:
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)   # a streaming kernel on another stream: CUs and memory queues are contended
+        ws1.compute_hoomd(0, n, pos[f].data_ptr(), chg[f].data_ptr(), img[f].data_ptr(), L, 2, prm, out[f].data_ptr())
+        if it % 10 == 9:
+            r = ws1.result()             # flag protocol, no device synchronisation
+            assert r.sequence == it + 1 and np.array_equal(np.array(r.dipole[:]), want_d[f])
+            bad += int(not torch.equal(out[f], want_f[f]))
+            out[f].fill_(float("nan"))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
+def test_graph_replays_on_changing_data_read_without_sync(ref, oracle_mod):
+    """Two captures (single-launch and two-launch), several replays each on data that changes between replays, results read
+    straight after graph.replay() with NO device synchronisation by the caller: a captured workspace must not trust the
+    host-visible flag (the sequence argument is frozen in the graph) and waits for the device itself."""
+    for tun in ({"persistent": 1}, {"persistent": 0}):
+        cfg = _random_cfg(40_000, seed=12, photon_at=39_999)
+        sysdef = to_device(cfg)
+        pd = sysdef.getParticleData()
+        comp = cavitymd.CavityForceComputeHIP(sysdef, 0.0091, 1e-3, 1.0)
+        for k, v in tun.items():
+            comp.workspace.set_tunable(k, v)
+        comp.compute(0)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            comp.compute(1)
+        cur = cfg
+        for rep in range(1, 5):
+            cur = synthetic.perturb(cur, rep, amplitude=0.5)
+            pd.getPositions().copy_(torch.from_numpy(oracle_mod.pack_pos(cur["position"], cur["typeid"])))
+            pd.getImages().copy_(torch.from_numpy(cur["image"]))
+            graph.replay()
+            e = np.array(comp.getEnergies())      # no torch.cuda.synchronize() in between
+            res = comp.getResult()
+            gpu = {"force": comp.getForceArray().cpu().numpy(), "energies": e, "dipole": np.array(res.dipole[:]),
+                   "photon_idx": res.photon_idx}
+            check_parity(cur, gpu, ref_eval(ref, oracle_mod, cur))

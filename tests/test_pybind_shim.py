@@ -19,7 +19,7 @@ def test_surface_matches_reference_exports(ext):
     for name in ("setParams", "getParams", "getHarmonicEnergy", "getCouplingEnergy", "getDipoleSelfEnergy",
                  "computeForces"):
         assert hasattr(cls, name)
-    assert ext.version() == 1
+    assert ext.version() == 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
