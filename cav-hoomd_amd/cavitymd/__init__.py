@@ -11,10 +11,10 @@ from .utils import PhysicalConstants, unwrap_positions
 from .forces import CavityForce
 from .compute import CavityForceComputeHIP
 from .state import BoxDim, ParticleData, SystemDefinition
-from . import _capi, observables, replicas, synthetic
+from . import _capi, observables, replicas, synthetic, thermostats
 
 __all__ = [
     "CavityForce", "CavityForceComputeHIP", "PhysicalConstants", "unwrap_positions", "BoxDim", "ParticleData",
-    "SystemDefinition", "observables", "replicas", "synthetic",
+    "SystemDefinition", "observables", "replicas", "synthetic", "thermostats",
 ]
 __version__ = "0.1.0"

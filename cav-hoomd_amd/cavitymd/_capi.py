@@ -55,11 +55,18 @@ class Result(ctypes.Structure):
                 ("reserved", ctypes.c_double)]
 
 
+class BussiReservoirState(ctypes.Structure):
+    """cavmd_bussi_reservoir (src/BussiReservoirThermostat.h:160-165)."""
+    _fields_ = [("reservoir_translational", ctypes.c_double), ("reservoir_rotational", ctypes.c_double),
+                ("instantaneous_translational", ctypes.c_double), ("instantaneous_rotational", ctypes.c_double)]
+
+
 # every symbol include/cavmd.h exports; tests check the header and the library against this list
 EXPORTED_SYMBOLS = (
     "cavmd_make_params", "cavmd_create", "cavmd_destroy", "cavmd_compute_hoomd", "cavmd_compute_soa",
     "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_set_wavevectors", "cavmd_density_field",
-    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_profile_enable", "cavmd_profile_read", "cavmd_profile_samples",
+    "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_kinetic_energy", "cavmd_scale_velocities",
+    "cavmd_bussi_rescale_factor", "cavmd_bussi_step", "cavmd_profile_enable", "cavmd_profile_read", "cavmd_profile_samples",
     "cavmd_set_tunable", "cavmd_get_tunable", "cavmd_device_info", "cavmd_error_string", "cavmd_version",
 )
 
@@ -119,6 +126,14 @@ def load():
         lib.cavmd_cavity_mode.restype = ci
         lib.cavmd_force_mass_sum.argtypes = [vp, vp, sz, vp, vp, P(dbl)]
         lib.cavmd_force_mass_sum.restype = ci
+        lib.cavmd_kinetic_energy.argtypes = [vp, vp, vp, vp, sz, P(dbl)]
+        lib.cavmd_kinetic_energy.restype = ci
+        lib.cavmd_scale_velocities.argtypes = [vp, vp, vp, vp, sz, dbl]
+        lib.cavmd_scale_velocities.restype = ci
+        lib.cavmd_bussi_rescale_factor.argtypes = [dbl] * 7 + [P(dbl)]
+        lib.cavmd_bussi_rescale_factor.restype = ci
+        lib.cavmd_bussi_step.argtypes = [P(BussiReservoirState), dbl, dbl, dbl, dbl, dbl, dbl, dbl, P(dbl * 4), P(dbl * 2)]
+        lib.cavmd_bussi_step.restype = ci
         lib.cavmd_profile_enable.argtypes = [vp, ci]
         lib.cavmd_profile_enable.restype = ci
         lib.cavmd_profile_read.argtypes = [vp, P(dbl * 3), P(ctypes.c_uint64)]
@@ -146,6 +161,22 @@ def error_string(status: int) -> str:
 def check(status: int, where: str = "") -> None:
     if status != CAVMD_OK:
         raise CavmdError(status, error_string(status), where)
+
+
+def bussi_rescale_factor(K, degrees_of_freedom, deltaT, set_T, tau, normal_variate, gamma_variate) -> float:
+    out = ctypes.c_double()
+    check(load().cavmd_bussi_rescale_factor(float(K), float(degrees_of_freedom), float(deltaT), float(set_T), float(tau),
+                                            float(normal_variate), float(gamma_variate), ctypes.byref(out)),
+          "cavmd_bussi_rescale_factor")
+    return float(out.value)
+
+
+def bussi_step(state: BussiReservoirState, K_trans, dof_trans, K_rot, dof_rot, deltaT, set_T, tau, variates):
+    v = (ctypes.c_double * 4)(*[float(x) for x in variates])
+    f = (ctypes.c_double * 2)()
+    check(load().cavmd_bussi_step(ctypes.byref(state), float(K_trans), float(dof_trans), float(K_rot), float(dof_rot),
+                                  float(deltaT), float(set_T), float(tau), ctypes.byref(v), ctypes.byref(f)), "cavmd_bussi_step")
+    return float(f[0]), float(f[1])
 
 
 def make_params(omegac: float, couplstr: float, phmass: float = 1.0) -> Params:
@@ -243,6 +274,18 @@ class Workspace:
         check(self._lib.cavmd_force_mass_sum(self._h, ctypes.c_void_p(stream), int(N), ctypes.c_void_p(force_ptr),
                                              ctypes.c_void_p(vel_ptr), ctypes.byref(out)), "cavmd_force_mass_sum")
         return float(out.value)
+
+    def kinetic_energy(self, stream: int, vel_ptr: int, members_ptr, n_members: int) -> float:
+        out = ctypes.c_double()
+        check(self._lib.cavmd_kinetic_energy(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr),
+                                             ctypes.c_void_p(members_ptr) if members_ptr else None, int(n_members),
+                                             ctypes.byref(out)), "cavmd_kinetic_energy")
+        return float(out.value)
+
+    def scale_velocities(self, stream: int, vel_ptr: int, members_ptr, n_members: int, alpha: float) -> None:
+        check(self._lib.cavmd_scale_velocities(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr),
+                                               ctypes.c_void_p(members_ptr) if members_ptr else None, int(n_members),
+                                               float(alpha)), "cavmd_scale_velocities")
 
     # -- measurement / tuning -----------------------------------------------------------------------
     def profile_enable(self, on: bool) -> None:

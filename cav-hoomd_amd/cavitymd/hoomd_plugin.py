@@ -22,29 +22,13 @@ from __future__ import annotations
 import hoomd
 from hoomd.logging import log
 
-from . import _capi
+from . import _capi, marshal
 from .forces import CavityForceSurface
 
 try:  # built only when HOOMD's headers were available at compile time
     from . import _cavitymd_hip  # type: ignore
 except ImportError:
     _cavitymd_hip = None
-
-
-def _cai(arr):
-    """(device pointer, byte stride between particles) of a HOOMD GPU local-array view."""
-    d = arr.__cuda_array_interface__
-    itemsize = int(d["typestr"][2:])
-    shape = d["shape"]
-    strides = d.get("strides")
-    if strides is None:
-        row = itemsize
-        for s in shape[1:]:
-            row *= s
-        stride0 = row
-    else:
-        stride0 = strides[0]
-    return int(d["data"][0]), int(stride0)
 
 
 class CavityForceCustomHIP(hoomd.md.force.Custom):
@@ -55,6 +39,7 @@ class CavityForceCustomHIP(hoomd.md.force.Custom):
         super().__init__(aniso=False)
         self._params = _capi.make_params(omegac, couplstr, phmass)
         self._ws = None
+        self._energies = marshal.EnergyCache()
 
     def setParams(self, omegac, couplstr, phmass=1.0):
         self._params = _capi.make_params(omegac, couplstr, phmass)
@@ -63,22 +48,25 @@ class CavityForceCustomHIP(hoomd.md.force.Custom):
         return self._params.as_dict()
 
     def getEnergies(self):
-        return self._ws.energies() if self._ws is not None else (0.0, 0.0, 0.0)
+        if self._ws is None:
+            return (0.0, 0.0, 0.0)
+        return self._energies.get(self._ws.energies)
 
     def set_forces(self, timestep):
+        # all marshalling is HOOMD-free and tested: cavitymd/marshal.py
         state = self._state
-        types = list(state.particle_types)
-        L_typeid = types.index("L") if "L" in types else -1
         with state.gpu_local_snapshot as snap, self.gpu_local_force_arrays as arrays:
             n = int(snap.particles.position.shape[0])
+            if n == 0:
+                self._energies.clear()          # the reference zeroes its energies when there is nothing to do
+                return
             if self._ws is None or n > self._ws.max_N:
                 self._ws = _capi.Workspace(max(n, 1))
-            box = snap.global_box.L
-            self._ws.compute_soa(
-                0,  # HOOMD-blue works on the null stream
-                n, _cai(snap.particles.position), _cai(snap.particles.typeid), _cai(snap.particles.image),
-                _cai(snap.particles.charge), (box[0], box[1], box[2]), L_typeid, self._params, _cai(arrays.force),
-                _cai(arrays.potential_energy))
+            marshal.set_forces_custom(self._ws, self._params, 0,  # HOOMD-blue works on the null stream
+                                      n, snap.particles.position, snap.particles.typeid, snap.particles.image,
+                                      snap.particles.charge, snap.global_box.L, state.particle_types, arrays.force,
+                                      arrays.potential_energy)
+            self._energies.bump()
 
 
 class HoomdCavityForce(CavityForceSurface, hoomd.md.force.Force):
@@ -99,19 +87,25 @@ class HoomdCavityForce(CavityForceSurface, hoomd.md.force.Force):
 
     def _attach_hook(self):
         sim = self._simulation
-        if not isinstance(sim.device, hoomd.device.GPU):
-            raise RuntimeError("cavitymd (HIP build) needs hoomd.device.GPU; it has no CPU implementation")
+        route = marshal.choose_route(_cavitymd_hip is not None, self._force_python, isinstance(sim.device, hoomd.device.GPU))
         sysdef = sim.state._cpp_sys_def
-        if _cavitymd_hip is not None and not self._force_python:
+        if route == marshal.ROUTE_HIP:
             self._force_impl = _cavitymd_hip.CavityForceComputeHIP(sysdef, self.omegac, self.couplstr, self.phmass)
             self._cpp_obj = self._force_impl
-            self._implementation = "hip"
         else:
+            # The Custom force is attached through HOOMD's own machinery, so that ITS _simulation / _cpp_obj are the ones
+            # gpu_local_force_arrays looks at (hoomd.md.force.Custom builds its CustomForceCompute in _attach_hook); this
+            # object then shares the inner C++ compute.  UNVERIFIED against a real HOOMD-blue, like the rest of this file.
             self._force_impl = CavityForceCustomHIP(self.couplstr, self.omegac, self.phmass)
-            self._force_impl._state = sim.state
-            self._cpp_obj = hoomd.md._md.CustomForceCompute(sysdef, self._force_impl.set_forces, False)
-            self._implementation = "hip_custom"
+            self._force_impl._attach(sim)
+            self._cpp_obj = self._force_impl._cpp_obj
+        self._implementation = route
         super()._attach_hook()
+
+    def _detach_hook(self):
+        impl, self._force_impl = self._force_impl, None
+        if impl is not None and hasattr(impl, "_detach"):
+            impl._detach()
 
     def _energy_component(self, k):
         impl = self._force_impl

@@ -862,6 +862,117 @@ int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream_, size_t N, const cav
     return CAVMD_OK;
 }
 
+int cavmd_kinetic_energy(cavmd_workspace* ws, void* stream_, const cavmd_double4* d_vel, const uint32_t* d_members,
+                         size_t n_members, double* out)
+{
+    if (!ws || !d_vel || !out || ((uintptr_t)d_vel & 15) || ((uintptr_t)d_members & 3))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (n_members > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY;
+    if (n_members == 0)
+    {
+        *out = 0.0;
+        return CAVMD_OK;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    if (!ws->d_fm_part)
+    {
+        CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_part, sizeof(double) * (2 * (size_t)ws->max_parts + 1)));
+        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_fm, sizeof(double), hipHostMallocDefault));
+    }
+    constexpr int kBlock = 256, kUnroll = 4;
+    const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 4);
+    double* d_out = ws->d_fm_part + 2 * (size_t)ws->max_parts;
+    hipLaunchKernelGGL((kinetic_partials_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part);
+    CAVMD_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((kinetic_fold_kernel<kBlock>), dim3(1), dim3(kBlock), 0, stream, ws->d_fm_part, g, d_out);
+    CAVMD_HIP_TRY(hipGetLastError());
+    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_fm, d_out, sizeof(double), hipMemcpyDeviceToHost, stream));
+    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
+    *out = *ws->h_fm;
+    return CAVMD_OK;
+}
+
+int cavmd_scale_velocities(cavmd_workspace* ws, void* stream_, cavmd_double4* d_vel, const uint32_t* d_members,
+                           size_t n_members, double alpha)
+{
+    if (!ws || !d_vel || ((uintptr_t)d_vel & 15) || ((uintptr_t)d_members & 3))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (n_members > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY;
+    if (n_members == 0)
+        return CAVMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    constexpr int kBlock = 256;
+    const unsigned g = grid_for(n_members, kBlock, ws->num_cu, 8);
+    hipLaunchKernelGGL((scale_velocities_kernel<kBlock>), dim3(g), dim3(kBlock), 0, stream, reinterpret_cast<v2d*>(d_vel),
+                       d_members, (unsigned)n_members, alpha);
+    return hip_status(hipGetLastError());
+}
+
+// ---- Bussi reservoir thermostat: the scalar rule (host arithmetic; the file is built with -ffp-contract=off) ---------
+int cavmd_bussi_rescale_factor(double K, double degrees_of_freedom, double deltaT, double set_T, double tau,
+                               double normal_variate, double gamma_variate, double* alpha)
+{
+    if (!alpha)
+        return CAVMD_ERR_INVALID_VALUE;
+    // src/BussiReservoirThermostat.h:183-184
+    if (degrees_of_freedom == 0)
+    {
+        *alpha = 1.0;
+        return CAVMD_OK;
+    }
+    // :186-190  c = exp(-dt / tau), 0 for tau == 0 (instantaneous thermalisation)
+    const double c = (tau != 0.0) ? exp(-deltaT / tau) : 0.0;
+    // :192-199  R ~ N(0,1); the sum of the other dof - 1 squared normals is 2 * Gamma((dof - 1) / 2, 1)
+    const double R = normal_variate;
+    const double r_gamma = (degrees_of_freedom > 1.0) ? 2.0 * gamma_variate : 0.0;
+    // :201-203
+    const double v = set_T / 2.0 / K;
+    const double term1 = v * (1.0 - c) * (r_gamma + R * R);
+    const double term2 = 2.0 * R * sqrt(v * (1.0 - c) * c);
+    // :206-207
+    const double magnitude = sqrt(c + term1 + term2);
+    // :211-213  sign[alpha] = sign[R + sqrt(c Nf K / ((1 - c) Kbar))], Bussi et al. 2009, eq. (A8)
+    const double K_bar = set_T * degrees_of_freedom / 2.0;
+    const double sign_term = R + sqrt(c * degrees_of_freedom * K / ((1.0 - c) * K_bar));
+    *alpha = (sign_term >= 0.0) ? magnitude : -magnitude;
+    return CAVMD_OK;
+}
+
+int cavmd_bussi_step(cavmd_bussi_reservoir* state, double K_translational, double dof_translational, double K_rotational,
+                     double dof_rotational, double deltaT, double set_T, double tau, const double variates[4],
+                     double factors[2])
+{
+    if (!state || !variates || !factors)
+        return CAVMD_ERR_INVALID_VALUE;
+    // src/BussiReservoirThermostat.h:45-48
+    if (deltaT == 0.0)
+    {
+        factors[0] = factors[1] = 1.0;
+        return CAVMD_OK;
+    }
+    // :57-61 "Bussi thermostat requires non-zero initial momenta."
+    if ((dof_translational != 0 && K_translational == 0) || (dof_rotational != 0 && K_rotational == 0))
+        return CAVMD_ERR_BAD_PARAMS;
+    double at = 1.0, ar = 1.0;
+    (void)cavmd_bussi_rescale_factor(K_translational, dof_translational, deltaT, set_T, tau, variates[0], variates[1], &at);
+    (void)cavmd_bussi_rescale_factor(K_rotational, dof_rotational, deltaT, set_T, tau, variates[2], variates[3], &ar);
+    // :86-95  energy handed to the reservoir = KE_old - KE_new = KE_old (1 - alpha^2)
+    const double delta_t = K_translational * (1.0 - at * at);
+    const double delta_r = K_rotational * (1.0 - ar * ar);
+    state->reservoir_translational += delta_t;
+    state->reservoir_rotational += delta_r;
+    state->instantaneous_translational = delta_t;
+    state->instantaneous_rotational = delta_r;
+    factors[0] = at;
+    factors[1] = ar;
+    return CAVMD_OK;
+}
+
 int cavmd_profile_enable(cavmd_workspace* ws, int on)
 {
     if (!ws)

@@ -279,10 +279,19 @@ __device__ __forceinline__ Scalars scalars_from_total(Accum acc, const PhotonRow
     dd_norm(acc.hy, acc.ly);
     dd_norm(acc.hz, acc.lz);
     double dx = acc.hx, dy = acc.hy, dz = acc.hz;
-    // all particles, L-typed included (the photon normally has charge 0, so this usually equals d)
-    sc.dtot[0] = dx + acc.sx;
-    sc.dtot[1] = dy + acc.sy;
-    sc.dtot[2] = dz + acc.sz;
+    // all particles, L-typed included (the photon normally has charge 0, so this usually equals d): the L-typed sum joins
+    // the double-double BEFORE the final rounding, so the low word is not thrown away when the two terms cancel
+    {
+        double th = acc.hx, tl = acc.lx;
+        dd_acc(th, tl, acc.sx);
+        sc.dtot[0] = th + tl;
+        th = acc.hy; tl = acc.ly;
+        dd_acc(th, tl, acc.sy);
+        sc.dtot[1] = th + tl;
+        th = acc.hz; tl = acc.lz;
+        dd_acc(th, tl, acc.sz);
+        sc.dtot[2] = th + tl;
+    }
     const int photon = (acc.lmin == INT_MAX) ? -1 : acc.lmin;
     const double g = prm.g, K = prm.K;
     double qx = 0.0, qy = 0.0, qz = 0.0, eh = 0.0, ec = 0.0, ed = 0.0, Dqx = 0.0, Dqy = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;

@@ -357,3 +357,79 @@ __global__ __launch_bounds__(BLOCK) void force_mass_fold_kernel(const double* __
         out[0] = acc.hi + acc.lo;
 }
 } // namespace cavmd
+
+// =====================================================================================================================
+// Row f4, thermostat side: the translational kinetic energy the Bussi reservoir thermostat consumes
+// (src/BussiReservoirThermostat.h:49-54: m_thermo->getTranslationalKineticEnergy() over the thermostat's group) and the
+// velocity rescaling its factor feeds (HOOMD's integration method multiplies the group's velocities by alpha).
+// KE = 1/2 sum_j m_j (vx^2 + vy^2 + vz^2) over the group's members, HOOMD's Scalar4 velocity array (mass in .w); the terms
+// are formed with one rounding per operation and summed in the same fixed-order compensated tree as the dipole.
+// members == nullptr: all particles 0 .. n-1 (streaming, 32 B per particle); else a device array of particle indices
+// (HOOMD's ParticleGroup index list), gathered 32 B per member.
+// =====================================================================================================================
+namespace cavmd
+{
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void kinetic_partials_kernel(const v2d* __restrict__ vel2,
+                                                                 const unsigned* __restrict__ members, unsigned n,
+                                                                 double* __restrict__ part /* [2][gridDim] */)
+{
+    constexpr unsigned TILE = BLOCK * UNROLL;
+    DD acc {0.0, 0.0};
+    const unsigned tiles = (n + TILE - 1) / TILE;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
+    {
+        const size_t base = (size_t)t * TILE + threadIdx.x;
+        v2d vxy[UNROLL], vzw[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+        {
+            const size_t k = base + (size_t)u * BLOCK;
+            const bool ok = k < n;
+            const v2d zero = {0.0, 0.0};
+            const size_t j = ok ? (members ? (size_t)members[k] : k) : 0;
+            vxy[u] = ok ? vel2[2 * j] : zero;
+            vzw[u] = ok ? vel2[2 * j + 1] : zero; // padding lanes: mass 0 -> term 0
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            dd_acc(acc.hi, acc.lo, vzw[u].y * ((vxy[u].x * vxy[u].x + vxy[u].y * vxy[u].y) + vzw[u].x * vzw[u].x));
+    }
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+    {
+        part[blockIdx.x] = acc.hi;
+        part[gridDim.x + blockIdx.x] = acc.lo;
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void kinetic_fold_kernel(const double* __restrict__ part, unsigned nparts,
+                                                             double* __restrict__ out)
+{
+    DD acc {0.0, 0.0};
+    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
+        dd_merge(acc.hi, acc.lo, part[p], part[nparts + p]);
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (threadIdx.x == 0)
+        out[0] = 0.5 * (acc.hi + acc.lo);
+}
+
+// v_j.xyz *= alpha for the members of the group (mass in .w untouched)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scale_velocities_kernel(v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                                 unsigned n, double alpha)
+{
+    for (size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (size_t)gridDim.x * BLOCK)
+    {
+        const size_t j = members ? (size_t)members[k] : k;
+        v2d xy = vel2[2 * j], zw = vel2[2 * j + 1];
+        xy.x *= alpha;
+        xy.y *= alpha;
+        zw.x *= alpha;
+        vel2[2 * j] = xy;
+        vel2[2 * j + 1] = zw;
+    }
+}
+} // namespace cavmd

@@ -8,7 +8,7 @@
 //             record of 8-byte {tag, 32-bit value} granules; the first block of every group of 16 consecutive blocks
 //             gathers its group's records, folds them (row_fold16) and publishes the group total; every block then
 //             gathers the <= 16 group totals and folds them.  Every block obtains the same bits; no float atomics.
-//             Block 0 publishes cavmd_result.
+//             The last block publishes cavmd_result.
 //   phase 2   every block writes the forces of its own tiles from the charges in LDS (dense 16-byte chunks): the
 //             charge array is not read a second time (84 instead of 92 bytes per particle cross the memory bus) and the
 //             second launch with its ramp, drain and re-fold prologue disappears.
@@ -21,7 +21,7 @@
 // every record) makes up to 1024 waves spin on the same 320 lines of the memory side -- measured 4.6 us per hand-off at
 // N = 1e6 whichever way the waiting was organised (profiles/r02/microbench_persistent_flat_*.txt); here a waiting block
 // polls 20 lines, from ONE wave.  The tag is the epoch word of the workspace, read from DEVICE memory at kernel start and
-// advanced by block 0 once it holds the total (every block has published by then, so every block has read it): a
+// advanced by the publishing block once it holds the total (every block has published by then, so every block has read it): a
 // captured launch replays correctly, nothing needs zeroing between launches.  Every spin is bounded: on a time-out the
 // block raises the sync_error word of the host-visible result block and fills its share of the force array with NaN.
 #pragma once
@@ -118,7 +118,7 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
             break;
         if (spins > kSpinLimit)
             return false;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j)
@@ -233,7 +233,11 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     __syncthreads();
     const bool any_failed = s_failed;
     CAVMD_PSTAMP(4);
-    const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, b == 0);
+    // The block that publishes cavmd_result (a system-scope release: ~0.6 us before its force stores can start) is the LAST
+    // block: it holds the fewest tiles (the ragged tail, or one tile less than the first blocks), so the detour is taken
+    // from its slack instead of from the kernel's critical path.
+    const bool publisher = (b == G - 1);
+    const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, publisher);
     if (tid == 0)
     {
         s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         s_mi[2] = any_failed;
         if (any_failed)
             __hip_atomic_store(&res_host->sync_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (b == 0)
+        if (publisher)
         {
             // every block has published, hence read the epoch: advance it for the next launch (0 is never a tag)
             __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

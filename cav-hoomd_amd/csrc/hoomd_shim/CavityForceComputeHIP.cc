@@ -3,8 +3,8 @@
 // What the reference's GPU class does per step and this one does not (src/CavityForceComputeGPU.cc:129-226):
 // four hipMemsets, one H2D and two blocking D2H copies, hipDeviceSynchronize, a host ArrayHandle on the force AND
 // position arrays (a full device->host migration under GlobalArray) and an O(N) host scan.  Here: acquire four
-// device handles, enqueue two kernels on the null stream (HOOMD-blue's stream), release.  Energies are fetched
-// lazily, once per timestep, when a getter is called (EnergyTracker polls them every step at period 1).
+// device handles, enqueue one kernel (two above ~5e6 particles) on the null stream (HOOMD-blue's stream), release.
+// Energies are fetched lazily, once per EVALUATION, when a getter is called (EnergyTracker polls them every step).
 #include "CavityForceComputeHIP.h"
 
 #include <stdexcept>
@@ -68,6 +68,14 @@ pybind11::dict CavityForceComputeHIP::getParams()
 void CavityForceComputeHIP::computeForces(uint64_t timestep)
     {
     const unsigned int N = m_pdata->getN();
+    m_eval_seq += 1; // the energies cached below belong to the PREVIOUS evaluation from here on
+    if (N == 0)
+        {
+        // nothing to compute: the reference zeroes its energies and returns (src/CavityForceCompute.cc:148-156)
+        m_energy[0] = m_energy[1] = m_energy[2] = 0.0;
+        m_energy_seq = m_eval_seq;
+        return;
+        }
     ensureWorkspace(N);
 
     // the CPU reference lets getTypeByName throw when no type is named 'L'; its GPU class zeroes the energies
@@ -104,15 +112,17 @@ void CavityForceComputeHIP::computeForces(uint64_t timestep)
                                   reinterpret_cast<cavmd_double4*>(d_force.data)),
               "cavmd_compute_hoomd");
         }
-    m_last_timestep = timestep;
+    (void)timestep;
     }
 
+// Keyed on the evaluation counter, not on the timestep: setParams(...) followed by sim.run(0) recomputes at the SAME
+// timestep and must not be answered from the cache.
 void CavityForceComputeHIP::fetchEnergies()
     {
-    if (m_energy_timestep == m_last_timestep && m_last_timestep != ~uint64_t(0))
+    if (m_energy_seq == m_eval_seq)
         return;
     check(cavmd_energies(m_ws, m_energy), "cavmd_energies");
-    m_energy_timestep = m_last_timestep;
+    m_energy_seq = m_eval_seq;
     }
 
 Scalar CavityForceComputeHIP::getHarmonicEnergy()

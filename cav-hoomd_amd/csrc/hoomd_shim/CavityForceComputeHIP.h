@@ -1,4 +1,4 @@
-// CavityForceComputeHIP.h -- HOOMD-blue 4.x ForceCompute whose computeForces() is libcavmd's two HIP kernels.
+// CavityForceComputeHIP.h -- HOOMD-blue 4.x ForceCompute whose computeForces() enqueues libcavmd's HIP kernels.
 //
 // COMPILE-GATED: built only when CMake finds HOOMD-blue (find_package(HOOMD)); the build/test image of this
 // repository has no HOOMD headers, so this file is UNBUILT and UNTESTED there.  It is the C++ half of the drop-in:
@@ -45,8 +45,8 @@ class PYBIND11_EXPORT CavityForceComputeHIP : public ForceCompute
     cavmd_params m_params;
     cavmd_workspace* m_ws = nullptr;
     size_t m_capacity = 0;
-    uint64_t m_energy_timestep = ~uint64_t(0); //!< timestep the cached energies belong to
-    uint64_t m_last_timestep = ~uint64_t(0);
+    uint64_t m_eval_seq = 0;   //!< evaluations enqueued so far (computeForces calls)
+    uint64_t m_energy_seq = 0; //!< evaluation the cached energies belong to (0 = none: the constructor's zeros)
     double m_energy[3] = {0.0, 0.0, 0.0};
     };
 

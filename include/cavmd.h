@@ -16,6 +16,10 @@
  *                                                                   cavmd_compute_soa
  *   getHarmonicEnergy/getCouplingEnergy/getDipoleSelfEnergy
  *                               src/CavityForceCompute.cc:58-71     cavmd_energies
+ *   BussiReservoirThermostat::getRescalingFactorsOne / compute_rescale_factor
+ *                               src/BussiReservoirThermostat.h:43-98, 177-225
+ *                                                                   cavmd_bussi_step / cavmd_bussi_rescale_factor,
+ *                                                                   cavmd_kinetic_energy, cavmd_scale_velocities
  *   CavityForceCompute::computeForces (the CPU semantics both follow)
  *                               src/CavityForceCompute.cc:134-208   (semantic contract, see below)
  *
@@ -214,6 +218,41 @@ CAVMD_API int cavmd_cavity_mode(cavmd_workspace* ws, void* stream, const cavmd_d
  * Enqueues two kernels and an 8-byte copy on `stream` and waits for them (the caller needs the number to set dt). */
 CAVMD_API int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream, size_t N, const cavmd_double4* d_net_force,
                                    const cavmd_double4* d_vel, double* out);
+
+/* ---- Bussi reservoir thermostat step ------------------------------------------------------- */
+/* Translational kinetic energy 1/2 sum_j m_j v_j.v_j of a particle group: what BussiReservoirThermostat reads from
+ * ComputeThermo (src/BussiReservoirThermostat.h:49-54).  d_vel is HOOMD's Scalar4 velocity array (mass in .w);
+ * d_members is a DEVICE array of n_members particle indices (HOOMD's ParticleGroup index list) or NULL for the particles
+ * 0 .. n_members-1.  Enqueues two kernels and an 8-byte copy on `stream` and waits for them. */
+CAVMD_API int cavmd_kinetic_energy(cavmd_workspace* ws, void* stream, const cavmd_double4* d_vel, const uint32_t* d_members,
+                                   size_t n_members, double* out);
+/* v_j.xyz *= alpha for the members of the group: what HOOMD's integration method does with the factor the thermostat
+ * returns.  Enqueues one kernel; no host synchronisation. */
+CAVMD_API int cavmd_scale_velocities(cavmd_workspace* ws, void* stream, cavmd_double4* d_vel, const uint32_t* d_members,
+                                     size_t n_members, double alpha);
+
+/* Reservoir accounting of BussiReservoirThermostat (src/BussiReservoirThermostat.h:160-165). */
+typedef struct cavmd_bussi_reservoir
+{
+    double reservoir_translational;     /* cumulative energy handed to the bath by the translational degrees of freedom */
+    double reservoir_rotational;
+    double instantaneous_translational; /* the same for the last step only */
+    double instantaneous_rotational;
+} cavmd_bussi_reservoir;
+
+/* The stochastic velocity-rescaling factor alpha of compute_rescale_factor (src/BussiReservoirThermostat.h:177-225),
+ * sign rule included, as a pure function of (K, Nf, dt, kT, tau) and the two random variates the reference draws:
+ * normal_variate ~ N(0,1), gamma_variate ~ Gamma((Nf - 1) / 2, 1) (ignored unless Nf > 1; drawn only then).
+ * Host arithmetic, no GPU needed.  Variate GENERATION is the caller's (HOOMD's RandomGenerator in the reference). */
+CAVMD_API int cavmd_bussi_rescale_factor(double K, double degrees_of_freedom, double deltaT, double set_T, double tau,
+                                         double normal_variate, double gamma_variate, double* alpha);
+/* One thermostat step, as getRescalingFactorsOne (src/BussiReservoirThermostat.h:43-98): factors[0] / [1] = translational /
+ * rotational alpha, reservoir counters updated with KE (1 - alpha^2).  variates = {normal_t, gamma_t, normal_r, gamma_r},
+ * in the order the reference consumes them.  deltaT == 0 -> {1, 1}, counters untouched;  a non-zero number of degrees
+ * of freedom with zero kinetic energy -> CAVMD_ERR_BAD_PARAMS (the reference throws "requires non-zero initial momenta"). */
+CAVMD_API int cavmd_bussi_step(cavmd_bussi_reservoir* state, double K_translational, double dof_translational,
+                               double K_rotational, double dof_rotational, double deltaT, double set_T, double tau,
+                               const double variates[4], double factors[2]);
 
 /* ---- measurement hooks (bench.py's roofline leg) ---------------------------------------------- */
 /* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */

@@ -7,6 +7,8 @@ Contents
     cavity_ref.c   C restatement of the reference CPU path (src/CavityForceCompute.cc:73-208 of
                    muhammadhasyim/cav-hoomd), built by ``oracle/Makefile`` into ``libcavref.so``.
     RefOracle      ctypes front end to it (this file).
+    bussi_ref.c    C restatement of the Bussi reservoir thermostat step with injected variates
+                   (src/BussiReservoirThermostat.h:43-98, 177-225) -> ``libbussiref.so`` / BussiOracle.
     numpy_mirror   second, independent restatement in numpy (vectorised maths, sequential sums
                    via math.fsum-free python loops only for tiny N) + exactly rounded sums.
 
@@ -38,8 +40,10 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (idempotent).  Returns the path of libcavref.so."""
     so = os.path.join(_HERE, "libcavref.so")
     src = os.path.join(_HERE, "cavity_ref.c")
+    bso, bsrc = os.path.join(_HERE, "libbussiref.so"), os.path.join(_HERE, "bussi_ref.c")
     stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) \
-        or not os.path.exists(os.path.join(_HERE, "libcavref_O3.so")) or not os.path.exists(os.path.join(_HERE, "libcavomp.so"))
+        or not os.path.exists(os.path.join(_HERE, "libcavref_O3.so")) or not os.path.exists(os.path.join(_HERE, "libcavomp.so")) \
+        or not os.path.exists(bso) or os.path.getmtime(bso) < os.path.getmtime(bsrc)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "all"], check=True)
     return so
@@ -162,6 +166,52 @@ class RefOracle:
             self.lib.cavref_time_evaluations(pos4.shape[0], pos4.ctypes.data, charge.ctypes.data, image.ctypes.data,
                                              float(box_L[0]), float(box_L[1]), float(box_L[2]), int(L_typeid),
                                              ctypes.byref(self._params(params)), force.ctypes.data, int(iters)))
+
+
+class BussiOracle:
+    """ctypes front end to libbussiref.so: the reference's Bussi reservoir step with injected variates
+    (src/BussiReservoirThermostat.h:43-98, 177-225) and the kinetic energy it consumes."""
+
+    def __init__(self):
+        build()
+        self.lib = ctypes.CDLL(os.path.join(_HERE, "libbussiref.so"))
+        dbl, vp, sz = ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+        self.lib.bussiref_rescale_factor.argtypes = [dbl] * 7
+        self.lib.bussiref_rescale_factor.restype = dbl
+        self.lib.bussiref_step.argtypes = [vp, dbl, dbl, dbl, dbl, dbl, dbl, dbl, vp, vp]
+        self.lib.bussiref_step.restype = ctypes.c_int
+        self.lib.bussiref_kinetic_energy.argtypes = [vp, vp, sz]
+        self.lib.bussiref_kinetic_energy.restype = dbl
+        self.lib.bussiref_kinetic_energy_exact.argtypes = [vp, vp, sz, vp]
+        self.lib.bussiref_kinetic_energy_exact.restype = dbl
+
+    def rescale_factor(self, K, dof, deltaT, set_T, tau, r_normal, gamma_variate) -> float:
+        return float(self.lib.bussiref_rescale_factor(K, dof, deltaT, set_T, tau, r_normal, gamma_variate))
+
+    def step(self, state: np.ndarray, K_trans, dof_trans, K_rot, dof_rot, deltaT, set_T, tau, variates):
+        """state: float64[4], updated in place.  Returns (alpha_translational, alpha_rotational) or raises where the
+        reference throws."""
+        v = np.ascontiguousarray(variates, dtype=np.float64)
+        f = np.zeros(2)
+        assert state.dtype == np.float64 and state.shape == (4,) and state.flags.c_contiguous
+        rc = self.lib.bussiref_step(state.ctypes.data, K_trans, dof_trans, K_rot, dof_rot, deltaT, set_T, tau, v.ctypes.data,
+                                    f.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("Bussi thermostat requires non-zero initial momenta.")
+        return float(f[0]), float(f[1])
+
+    def kinetic_energy(self, vel4: np.ndarray, members=None, exact: bool = False):
+        vel4 = np.ascontiguousarray(vel4, dtype=np.float64)
+        if members is None:
+            mp, n = None, vel4.shape[0]
+        else:
+            members = np.ascontiguousarray(members, dtype=np.uint32)
+            mp, n = members.ctypes.data, members.shape[0]
+        if exact:
+            lo = ctypes.c_double()
+            hi = self.lib.bussiref_kinetic_energy_exact(vel4.ctypes.data, mp, n, ctypes.addressof(lo))
+            return float(hi), float(lo.value)
+        return float(self.lib.bussiref_kinetic_energy(vel4.ctypes.data, mp, n))
 
 
 def allowed_cpus() -> int:
