@@ -70,7 +70,9 @@ struct cavmd_workspace
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     int map_reverse = -1;         // -1 auto, 1: the force map walks its tiles last-to-first, 0: first-to-last
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
-    int persistent = -1;          // -1 auto, 0 never, 1 whenever the charges of a block's tiles fit in LDS: ONE launch per evaluation
+    int persistent = -1;          // -1 auto, 0 never, 1 whenever the grid is <= 256 blocks: ONE launch per evaluation
+    int persistent_balanced = -1; // partition of the particles over the blocks of the single-launch kernel: -1 auto, 0 tiles
+                                  // dealt round-robin (the two-launch path's partition), 1 contiguous, equal shares
     // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
     unsigned long long* d_granules = nullptr;
     unsigned* d_epoch = nullptr;
@@ -190,6 +192,14 @@ bool persistent_auto(size_t N)
 {
     (void)N;
     return true;
+}
+// Contiguous equal shares measured SLOWER than tiles dealt round-robin wherever the streaming matters (21.5 vs 20.3 us at
+// N = 1e6, 63.8 vs 57.8 at 4e6: 256 sequential streams a fixed distance apart load the HBM channels less evenly than one
+// 4 MB window that all blocks sweep together); only 3e5 gained (12.0 vs 12.2).  Kept as a tunable, off.
+bool persistent_balanced_auto(size_t N)
+{
+    (void)N;
+    return false;
 }
 
 unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_cu)
@@ -451,24 +461,36 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
     const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
 
-    // ---- ONE launch (cavmd_persistent_kernel.hpp): the same grid and tiles as launch 1 below, so the same partials and
-    // the same fold, bit for bit; possible while the charges of a block's tiles fit in LDS and the whole grid is resident
-    // at once (g1 <= CUs x blocks per CU by construction; LDS and registers admit that many blocks per CU).
+    // ---- ONE launch (cavmd_persistent_kernel.hpp): the same grid as launch 1 below; with the strided partition also the
+    // same tiles, hence the same partials and (same fold) the same bits as two launches.  Needs the whole grid resident at
+    // once: g1 <= CUs x blocks per CU by construction, <= 256 blocks (the two-level all-reduce), LDS and registers admit
+    // that many blocks per CU.  The charges of a block's first lds_slots tiles stay in LDS; tiles beyond (N >~ 5e6) are
+    // read a second time.
     {
         const size_t tile = (size_t)kReduceBlock * unroll;
-        const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
-        const size_t lds = slots * tile * sizeof(double);
-        const bool resident = lds <= kPersistMaxLds && g1 <= kMaxPersistGrid
-                              && (size_t)ws->reduce_blocks_per_cu * (lds + 1024) <= (size_t)160 * 1024
-                              && ws->reduce_blocks_per_cu <= 4;
-        if (resident && (ws->persistent > 0 || (ws->persistent < 0 && persistent_auto(N))))
+        const bool balanced = ws->persistent_balanced < 0 ? persistent_balanced_auto(N) : (ws->persistent_balanced != 0);
+        size_t slots;
+        if (balanced)
+        {
+            const size_t units = (N + kWave - 1) / kWave;
+            slots = (((units + g1 - 1) / g1) * kWave + tile - 1) / tile; // the largest share, in tiles (ragged one included)
+        }
+        else
+            slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        const size_t cap_slots = (kPersistMaxLds / (size_t)ws->reduce_blocks_per_cu - 1024) / (tile * sizeof(double));
+        const size_t lds_slots = slots < cap_slots ? slots : cap_slots;
+        const size_t lds = lds_slots * tile * sizeof(double);
+        const bool resident = g1 <= kMaxPersistGrid && ws->reduce_blocks_per_cu <= 4;
+        // auto: only while every tile of a block fits in LDS.  With overflow tiles the second phase (one block per CU, loads
+        // and stores of a tile back to back) is latency-bound: 170 us against 138 us for two launches at N = 1e7.
+        if (resident && (ws->persistent > 0 || (ws->persistent < 0 && slots <= cap_slots && persistent_auto(N))))
         {
             ws->sequence += 1;
             const AosInputT<2> inx {in.pos2, in.charge, in.image};
             const SyncState sync {ws->d_granules, ws->d_epoch};
 #define CAVMD_LAUNCH_PERSIST(UNR, NTS)                                                                               \
     st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, UNR, NTS>, g1, kPersistBlock, inx, n, Lx, Ly, Lz, \
-                       dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2);
+                       dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2, (unsigned)lds_slots, balanced);
             if (unroll == 2)
             {
                 if (nt_store)
@@ -1100,6 +1122,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->persistent = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "persistent_balanced"))
+    {
+        if (value < -1 || value > 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->persistent_balanced = value;
+        return CAVMD_OK;
+    }
     return CAVMD_ERR_INVALID_VALUE;
 }
 
@@ -1123,6 +1152,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->small_system_max_n;
     else if (!strcmp(name, "persistent"))
         *value = ws->persistent;
+    else if (!strcmp(name, "persistent_balanced"))
+        *value = ws->persistent_balanced;
     else
         return CAVMD_ERR_INVALID_VALUE;
     return CAVMD_OK;

@@ -1,4 +1,4 @@
-// cavmd_persistent_kernel.hpp -- the whole cavity-force evaluation in ONE launch (2048 < N <~ 5e6).
+// cavmd_persistent_kernel.hpp -- the whole cavity-force evaluation in ONE launch (N > 2048).
 //
 //   phase 1   every block streams its tiles (pos 32 + charge 8 + image 12 B per particle) exactly as
 //             dipole_partials_kernel does -- same tile assignment, same double-double accumulation, same block tree,
@@ -9,9 +9,10 @@
 //             gathers its group's records, folds them (row_fold16) and publishes the group total; every block then
 //             gathers the <= 16 group totals and folds them.  Every block obtains the same bits; no float atomics.
 //             The last block publishes cavmd_result.
-//   phase 2   every block writes the forces of its own tiles from the charges in LDS (dense 16-byte chunks): the
-//             charge array is not read a second time (84 instead of 92 bytes per particle cross the memory bus) and the
-//             second launch with its ramp, drain and re-fold prologue disappears.
+//   phase 2   every block writes the forces of its own tiles from the charges in LDS (dense 16-byte chunks): up to ~5e6
+//             particles the charge array is not read a second time (84 instead of 92 bytes per particle cross the memory
+//             bus; beyond that the tiles that do not fit in LDS are re-read) and the second launch with its ramp, drain and
+//             re-fold prologue disappears.
 //
 // Inter-workgroup protocol (cdna_hip_programming.md, Guideline 16, form R2 "the data is the flag"): each granule is ONE
 // naturally aligned 8-byte relaxed agent-scope atomic (global_store/load_dwordx2 sc1), carries its own tag and is
@@ -139,6 +140,47 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
     return true;
 }
 
+// The particles of one block: `nfull` full tiles at first, first + step, ... and one ragged tile of `tail_count` particles
+// at `tail_base`.  Two partitions of the N particles over the G blocks:
+//   strided   tile t belongs to block t % G (exactly dipole_partials_kernel's assignment: the single-launch kernel then
+//             produces the two-launch path's partials bit for bit -- what the hand-off's parity test leans on);
+//   balanced  block b takes the contiguous 64-particle units [b U / G, (b + 1) U / G), U = ceil(N / 64): every block gets
+//             the same number of particles to within 64, instead of differing by a whole 512-particle tile (one tile is
+//             13 % of a block's share at N = 1e6).
+struct BlockRange
+{
+    size_t first, step, tail_base;
+    unsigned nfull, tail_count;
+};
+template <unsigned TILE>
+__device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsigned b, bool balanced)
+{
+    BlockRange r;
+    if (balanced)
+    {
+        const unsigned long long U = ((unsigned long long)N + kWave - 1) / kWave;
+        const size_t s = (size_t)(U * b / G) * kWave;
+        size_t e = (size_t)(U * (b + 1) / G) * kWave;
+        e = e < N ? e : N;
+        const size_t n = e > s ? e - s : 0;
+        r.first = s;
+        r.step = TILE;
+        r.nfull = (unsigned)(n / TILE);
+        r.tail_base = s + (size_t)r.nfull * TILE;
+        r.tail_count = (unsigned)(n - (size_t)r.nfull * TILE);
+    }
+    else
+    {
+        const unsigned full_tiles = N / TILE;
+        r.first = (size_t)b * TILE;
+        r.step = (size_t)G * TILE;
+        r.nfull = full_tiles > b ? (full_tiles - b + G - 1) / G : 0;
+        r.tail_base = (size_t)full_tiles * TILE;
+        r.tail_count = (b == full_tiles % G) ? (unsigned)(N - r.tail_base) : 0;
+    }
+    return r;
+}
+
 extern __shared__ __attribute__((aligned(16))) double s_dyn_charge[];
 
 template <int BLOCK, int UNROLL, bool NT_STORE>
@@ -146,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
                                                                   DeviceParams prm, int L_typeid, SyncState st,
                                                                   uint64_t sequence, cavmd_result* __restrict__ res,
                                                                   HostResult* __restrict__ res_host,
-                                                                  v2d* __restrict__ force2)
+                                                                  v2d* __restrict__ force2, unsigned lds_slots, bool balanced)
 {
     constexpr unsigned TILE = BLOCK * UNROLL; // particles per tile; the same tile is 2 * TILE force chunks
     constexpr int MU = 2 * UNROLL;            // 16-byte chunk stores per thread and tile
@@ -160,32 +202,34 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     const unsigned tag = __hip_atomic_load(st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
 
-    // ---- phase 1: partial dipole of this block's tiles, charges parked in LDS ------------------------------------------
+    // ---- phase 1: partial dipole of this block's tiles; the charges of its first lds_slots tiles are parked in LDS ---------
     Accum acc;
-    const unsigned full_tiles = N / TILE;
-    unsigned slot = 0; // tiles of this block so far
-    for (unsigned t = b; t < full_tiles; t += G, ++slot)
+    const BlockRange rg = block_range<TILE>(N, G, b, balanced);
+    for (unsigned slot = 0; slot < rg.nfull; ++slot)
     {
-        const size_t base = (size_t)t * TILE + tid;
+        const size_t base = rg.first + (size_t)slot * rg.step + tid;
         TileRegs<AosInputT<2>, UNROLL> A;
         tile_load<AosInputT<2>, BLOCK, UNROLL>(in, base, A);
         __builtin_amdgcn_sched_barrier(0);
+        if (slot < lds_slots)
+        {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            s_charge[slot * TILE + u * BLOCK + tid] = A.raw[u].c;
+            for (int u = 0; u < UNROLL; ++u)
+                s_charge[slot * TILE + u * BLOCK + tid] = A.raw[u].c;
+        }
         tile_accumulate<AosInputT<2>, BLOCK, UNROLL>(A, base, Lx, Ly, Lz, L_typeid, acc);
     }
-    const bool has_tail = (b == full_tiles % G) && (full_tiles * TILE < N);
-    if (has_tail)
+    if (rg.tail_count)
     {
-        const size_t base = (size_t)full_tiles * TILE + tid;
+        const size_t base = rg.tail_base + tid;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
         {
-            const size_t i = base + (size_t)u * BLOCK;
+            const unsigned o = u * BLOCK + tid;
             double c = 0.0;
-            if (i < N)
+            if (o < rg.tail_count)
             {
+                const size_t i = base + (size_t)u * BLOCK;
                 const typename AosInputT<2>::Raw r = in.load(i);
                 const double rx = AosInputT<2>::x(r) + (double)r.ix * Lx;
                 const double ry = AosInputT<2>::y(r) + (double)r.iy * Ly;
@@ -193,7 +237,8 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
                 acc.add((unsigned)i, rx, ry, rz, r.c, AosInputT<2>::tag(r), L_typeid);
                 c = r.c;
             }
-            s_charge[slot * TILE + u * BLOCK + tid] = c;
+            if (rg.nfull < lds_slots)
+                s_charge[rg.nfull * TILE + o] = c;
         }
     }
     CAVMD_PSTAMP(1);
@@ -305,14 +350,24 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     const double ng = -prm.g;
     const size_t pchunk = 2 * (size_t)m.photon; // photon's first chunk
     const bool odd = tid & 1;                   // BLOCK is even, so the half is fixed per thread
-    slot = 0;
-    for (unsigned t = b; t < full_tiles; t += G, ++slot)
+    for (unsigned slot = 0; slot < rg.nfull; ++slot)
     {
-        const size_t base = (size_t)t * 2 * TILE + tid;
+        const size_t p0 = rg.first + (size_t)slot * rg.step; // first particle of the tile
+        const size_t base = 2 * p0 + tid;
         double c[MU];
+        if (slot < lds_slots)
+        {
 #pragma unroll
-        for (int u = 0; u < MU; ++u)
-            c[u] = s_charge[slot * TILE + ((u * BLOCK + tid) >> 1)];
+            for (int u = 0; u < MU; ++u)
+                c[u] = s_charge[slot * TILE + ((u * BLOCK + tid) >> 1)];
+        }
+        else
+        {
+            // beyond the LDS budget (N >~ 5e6): these charges are read a second time, as the two-launch path reads all of them
+#pragma unroll
+            for (int u = 0; u < MU; ++u)
+                c[u] = __builtin_nontemporal_load(in.charge + p0 + ((u * BLOCK + tid) >> 1));
+        }
 #pragma unroll
         for (int u = 0; u < MU; ++u)
         {
@@ -325,16 +380,18 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             store_chunk<NT_STORE>(force2 + k, v);
         }
     }
-    if (has_tail)
+    if (rg.tail_count)
     {
-        const size_t base = (size_t)full_tiles * 2 * TILE + tid;
+        const size_t base = 2 * rg.tail_base + tid;
 #pragma unroll
         for (int u = 0; u < MU; ++u)
         {
-            const size_t k = base + (size_t)u * BLOCK;
-            if (k < nchunks)
+            const unsigned o = (u * BLOCK + tid) >> 1; // particle within the ragged tile
+            if (o < rg.tail_count)
             {
-                const double s = ng * s_charge[slot * TILE + ((u * BLOCK + tid) >> 1)];
+                const size_t k = base + (size_t)u * BLOCK;
+                const double cc = rg.nfull < lds_slots ? s_charge[rg.nfull * TILE + o] : in.charge[rg.tail_base + o];
+                const double s = ng * cc;
                 v2d v = {s * m.Dqx, s * m.Dqy};
                 v = odd ? zero : v;
                 if ((k | 1) == (pchunk | 1))

@@ -128,17 +128,20 @@ int main(int argc, char** argv)
                      else
                          hipLaunchKernelGGL((force_map_aos_fused_kernel<256, 4, false>), dim3(g2), dim3(256), 0, st, in0(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f], false);
                  }, {}});
-    auto persist = [&](int f, int bpc) {
+    auto persist = [&](int f, int bpc, bool balanced = false) {
         const unsigned g1 = grid(N, 256 * unroll, bpc);
         const size_t tile = 256 * unroll;
-        const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
-        const size_t lds = slots * tile * 8;
-        if (lds > 156 * 1024) { fprintf(stderr, "LDS %zu too large\n", lds); exit(1); }
-#define PL(UNR, NTS) hipLaunchKernelGGL((cavity_persistent_kernel<256, UNR, NTS>), dim3(g1), dim3(256), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f])
+        size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        if (balanced) { const size_t units = (N + 63) / 64; slots = (((units + g1 - 1) / g1) * 64 + tile - 1) / tile; }
+        const size_t cap = (156 * 1024 - 1024) / (tile * 8);
+        const unsigned lds_slots = (unsigned)std::min(slots, cap);
+        const size_t lds = (size_t)lds_slots * tile * 8;
+#define PL(UNR, NTS) hipLaunchKernelGGL((cavity_persistent_kernel<256, UNR, NTS>), dim3(g1), dim3(256), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f], lds_slots, balanced)
         if (unroll == 2) { if (nts) PL(2, true); else PL(2, false); }
         else { if (nts) PL(1, true); else PL(1, false); }
     };
-    V.push_back({"single launch (two-level in-launch all-reduce)", [&](int f) { persist(f, 1); }, {}});
+    V.push_back({"single launch, tiles dealt round-robin", [&](int f) { persist(f, 1, false); }, {}});
+    V.push_back({"single launch, balanced contiguous shares", [&](int f) { persist(f, 1, true); }, {}});
 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -175,7 +178,7 @@ int main(int argc, char** argv)
         std::vector<std::vector<double>> med(8), mx(8), mnv(8);
         for (int rep = 0; rep < 30; ++rep)
         {
-            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1); // steady state: the stamps are those of the last launch
+            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, true); // steady state: the stamps are those of the last launch
             CHECK(hipDeviceSynchronize());
             std::vector<unsigned long long> h(4096 * kStampSlots);
             CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
@@ -204,7 +207,7 @@ int main(int argc, char** argv)
                 med[k].push_back(v[g1 / 2]); mx[k].push_back(v.back()); mnv[k].push_back(v.front());
             }
         }
-        printf("time line, single launch, grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
+        printf("time line, single launch (balanced shares), grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
                g1);
         for (int k : {0, 1, 2, 7, 3, 4, 5, 6})
         {

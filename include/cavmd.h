@@ -277,9 +277,12 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
  *   "map_reverse"          -1..1   -1 auto by N, 1: the force map walks its tiles last-to-first, 0: first-to-last
  *   "small_system_max_n"   0..2^20 at or below this N one single-block launch does the whole evaluation (0 = never)
- *   "persistent"           -1..1   ONE launch per evaluation (reduction, in-launch gather of the partials, force map from
- *                                  charges kept in LDS): 1 whenever a block's charges fit in LDS (N <~ 5e6), 0 never,
- *                                  -1 auto (where it measured faster).  Same partials, same fold, same bits as two launches.
+ *   "persistent"           -1..1   ONE launch per evaluation (reduction, in-launch all-reduce of the partials, force map from
+ *                                  charges kept in LDS): 1 whenever the grid is <= 256 blocks, 0 never (two launches),
+ *                                  -1 auto (where it measured faster: everywhere above small_system_max_n).
+ *   "persistent_balanced"  -1..1   partition of the particles over the blocks of the single-launch kernel: 0 tiles dealt
+ *                                  round-robin (the two-launch path's partition: then also its bits), 1 contiguous equal
+ *                                  shares, -1 auto
  * Returns CAVMD_ERR_INVALID_VALUE for an unknown name or an out-of-range value.  None of them changes results
  * beyond the last bit of the dipole (different but fixed summation trees). */
 CAVMD_API int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value);

@@ -238,7 +238,9 @@ def test_config5_replicas_seeds_1_to_8(ref, oracle_mod, replica):
     stats = check_parity(cfg, one, refout)
     two = gpu_eval(cfg, {"persistent": 0})
     check_parity(cfg, two, refout)
-    assert np.array_equal(one["force"], two["force"]) and np.array_equal(one["energies"], two["energies"])
+    strided = gpu_eval(cfg, {"persistent": 1, "persistent_balanced": 0})
+    assert np.array_equal(strided["force"], two["force"]) and np.array_equal(strided["energies"], two["energies"])
+    assert np.all(np.abs(one["dipole"] - two["dipole"]) <= np.spacing(np.abs(two["dipole"])))
     print(f"\nreplica {replica + 1}: {stats}")
 
 
@@ -395,7 +397,7 @@ def test_tunables_do_not_change_the_physics(ref, oracle_mod):
                 {"map_blocks_per_cu": 16, "map_nt_store": 1}, {"map_nt_store": 0}, {"fused_finalize": 0}, {"fused_finalize": 0, "reduce_blocks_per_cu": 8},
                 {"reduce_nt_load": 0}, {"reduce_nt_load": 2}, {"reduce_blocks_per_cu": 3}, {"small_system_max_n": 1 << 20}, {"map_reverse": 1}, {"map_reverse": 0, "map_blocks_per_cu": 1},
                 {"map_reverse": 1, "map_blocks_per_cu": 7}, {"fused_finalize": 1, "reduce_blocks_per_cu": 5, "map_nt_store": 1},
-                {"persistent": 0}, {"persistent": 1, "reduce_blocks_per_cu": 2},
+                {"persistent": 0}, {"persistent": 1, "persistent_balanced": 0}, {"persistent": 1, "reduce_blocks_per_cu": 2},
                 {"persistent": 1, "reduce_blocks_per_cu": 4, "map_nt_store": 0}):
         out = gpu_eval(cfg, tun)
         check_parity(cfg, out, refout)
@@ -530,9 +532,11 @@ def test_snapshot_layout_entry_point(ref, oracle_mod, hoomd_views):
 
 
 def test_both_layouts_give_identical_bits():
-    for n, tun in ((123_457, None), (20_001, None), (1_500, {"small_system_max_n": 0})):
+    for n, tun in ((123_457, {}), (20_001, {}), (1_500, {"small_system_max_n": 0})):
         cfg = _random_cfg(n, seed=77, photon_at=n - 1)
-        a = gpu_eval(cfg, tun)     # (the single-block path exists for the AoS layout only: switched off for the small case)
+        # (the single-block path exists for the AoS layout only: switched off for the small case; the snapshot layout
+        # runs as two launches, so the AoS side uses the same partition of the particles)
+        a = gpu_eval(cfg, dict(tun, persistent_balanced=0))
         b = _soa_eval(cfg, hoomd_views=False)
         assert np.array_equal(a["dipole"], b["dipole"]) and np.array_equal(a["energies"], b["energies"])
         assert np.array_equal(a["force"], b["force"])
@@ -623,20 +627,27 @@ def test_cavity_force_object_end_to_end(ref, oracle_mod):
 
 
 # ---- the single-launch evaluation (cavmd_persistent_kernel.hpp) ----------------------------------------------------------------
-@pytest.mark.parametrize("n", [2049, 3000, 10_000, 65_537, 131_073, 262_145, 1_000_001, 3_000_017])
-def test_single_launch_gives_the_bits_of_two_launches(n):
-    """Same grid, same tiles, same fold order: the one-launch kernel must reproduce the two-launch path bit for bit
-    (forces, dipole high and low words, energies, photon)."""
+@pytest.mark.parametrize("n", [2049, 3000, 10_000, 65_537, 131_073, 262_145, 1_000_001, 3_000_017, 6_000_001])
+def test_single_launch_gives_the_bits_of_two_launches(ref, oracle_mod, n):
+    """With the tiles dealt round-robin (the two-launch path's partition) the one-launch kernel has the same grid, the same
+    tiles and the same fold order: it must reproduce the two-launch path bit for bit (forces, dipole high and low words,
+    energies, photon) -- any stale, torn or misplaced granule of the in-launch all-reduce would change bits.  With balanced
+    contiguous shares (a tunable; measured slower, off by default) the partials differ, so the dipole may move by an ulp; that variant is checked against
+    the oracle with the full contract.  6e6 particles: more tiles than a block's LDS holds, the overflow is re-read."""
     for photon_at in sorted({0, n // 3, n - 1}):
         cfg = _random_cfg(n, seed=n + photon_at, photon_at=photon_at)
         two = gpu_eval(cfg, {"persistent": 0})
-        for tun in ({"persistent": 1},):
-            one = gpu_eval(cfg, tun)
-            assert one["result"].n_partials == two["result"].n_partials
-            assert np.array_equal(one["force"], two["force"])
-            assert np.array_equal(one["dipole"], two["dipole"]) and np.array_equal(one["dipole_lo"], two["dipole_lo"])
-            assert np.array_equal(one["energies"], two["energies"]) and one["photon_idx"] == two["photon_idx"] == photon_at
-            assert np.array_equal(np.array(one["result"].total_dipole[:]), np.array(two["result"].total_dipole[:]))
+        one = gpu_eval(cfg, {"persistent": 1, "persistent_balanced": 0})
+        assert one["result"].n_partials == two["result"].n_partials
+        assert np.array_equal(one["force"], two["force"])
+        assert np.array_equal(one["dipole"], two["dipole"]) and np.array_equal(one["dipole_lo"], two["dipole_lo"])
+        assert np.array_equal(one["energies"], two["energies"]) and one["photon_idx"] == two["photon_idx"] == photon_at
+        assert np.array_equal(np.array(one["result"].total_dipole[:]), np.array(two["result"].total_dipole[:]))
+        bal = gpu_eval(cfg, {"persistent": 1, "persistent_balanced": 1})
+        assert bal["photon_idx"] == photon_at
+        assert np.all(np.abs(bal["dipole"] - two["dipole"]) <= np.spacing(np.abs(two["dipole"])))
+        if photon_at == n - 1 and n <= 3_000_017:
+            check_parity(cfg, bal, ref_eval(ref, oracle_mod, cfg))
 
 
 def test_single_launch_degenerate_inputs(ref, oracle_mod):
@@ -647,12 +658,17 @@ def test_single_launch_degenerate_inputs(ref, oracle_mod):
     cfg = _random_cfg(50_000, seed=9, photon_at=100)
     for extra in (99, 101, 25_000, 49_999):
         cfg["typeid"][extra] = 2
-    one, two = gpu_eval(cfg, {"persistent": 1}), gpu_eval(cfg, {"persistent": 0})
+    one, two = gpu_eval(cfg, {"persistent": 1, "persistent_balanced": 0}), gpu_eval(cfg, {"persistent": 0})
     assert one["photon_idx"] == 99 and one["n_L"] == 5
     assert np.array_equal(one["force"], two["force"]) and np.array_equal(one["dipole"], two["dipole"])
     refout = ref_eval(ref, oracle_mod, cfg)
     S = force_scales(cfg, refout)
     assert np.all(np.abs(one["force"][:, :3] - refout["force"][:, :3]) <= 1e-10 * S[:, None] + 1e-300)
+    bal = gpu_eval(cfg, {"persistent": 1, "persistent_balanced": 1})
+    assert bal["photon_idx"] == 99 and bal["n_L"] == 5
+    assert np.all(np.abs(bal["force"][:, :3] - refout["force"][:, :3]) <= 1e-10 * S[:, None] + 1e-300)
+    for i in (101, 25_000, 49_999):
+        assert not bal["force"][i].any()
 
 
 def test_single_launch_hand_off_under_load_and_reuse():
@@ -679,6 +695,7 @@ def test_single_launch_hand_off_under_load_and_reuse():
         want_d.append(np.array(ws2.result().dipole[:]))
     ws1 = _capi.Workspace(n)
     ws1.set_tunable("persistent", 1)
+    ws1.set_tunable("persistent_balanced", 0)   # the two-launch path's partition, so that every bit must agree
     side = torch.cuda.Stream()
     junk = torch.empty(64 * 2**20, dtype=torch.float32, device=dev)
     out = [torch.empty((n, 4), dtype=torch.float64, device=dev) for _ in range(frames)]
