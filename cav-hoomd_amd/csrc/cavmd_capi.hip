@@ -36,7 +36,10 @@ constexpr size_t kMaxSamples = 4096;
 constexpr int kSmallBlock = 256;
 constexpr int kSmallSystemMaxN = 2048;         // single-block path wins below ~3000 particles (7.4 vs 11.0 us at N = 501, 9.2 vs 11.4 at 2001)
 constexpr size_t kNtStoreMinN = 200000;       // force stores: neutral at 1e5, -3.6 % at 3e5, -4.3 % at 1e6, -5.8 % at 1e7
-constexpr size_t kChargeTemporalMaxN = 5000000; // measured crossover: temporal charge loads win up to 4e6, tie at 6e6, lose at 1e7
+constexpr size_t kChargeTemporalMaxN = 25000000; // charges stay temporal while the 8 N bytes fit in the 256 MiB Infinity Cache
+                                                 // next to the streams: re-measured in round 2 (the round-1 crossover at
+                                                 // 5e6 dated from before the scratch-traffic fix): -8 % per evaluation at
+                                                 // 6e6 and 1e7, -5 % at 2e7, tie at 5e7 (profiles/r02/ab_two_launch_knobs.txt)
 constexpr int kPersistBlock = 256;
 constexpr size_t kPersistMaxLds = 156 * 1024; // dynamic LDS of the single-launch kernel (charges of a block's tiles); 160 KiB per CU
 
@@ -516,9 +519,8 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     }
 
     // Load policy of the reduction.  pos and image are read once per evaluation: non-temporal.  charge is read again
-    // by the force map: keeping it temporal lets the map hit it in the Infinity Cache while 8 N bytes are small
-    // (measured -4 % per evaluation at N = 1e6, -3 % at 4e6, 0 at 6e6) but costs +16 % at N = 1e7, where it only
-    // evicts useful lines.
+    // by the force map: keeping it temporal lets the map find it in the Infinity Cache while 8 N bytes fit there
+    // (measured per evaluation: -8 % at N = 6e6 and 1e7, -5 % at 2e7, tie at 5e7); non-temporal above.
     int nt = ws->reduce_nt_load;
     if (nt < 0)
         nt = (N <= kChargeTemporalMaxN) ? 1 : 2;
@@ -551,7 +553,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     // Reverse tile order in the force map: the charge lines the reduction touched last are then asked for first.  It only
     // matters where the per-XCD share of the charges (N bytes) is about the size of an XCD's 4 MiB L2: -3.3 % per
     // evaluation at N = 4e6, neutral at 3e5 / 1e6 / 2e6 / 1e7 (scripts/ab_tunable.py map_reverse 0 1 ...).
-    const bool map_reverse = ws->map_reverse < 0 ? (N > 2500000 && N <= kChargeTemporalMaxN) : (ws->map_reverse != 0);
+    const bool map_reverse = ws->map_reverse < 0 ? (N > 2500000 && N <= 5000000) : (ws->map_reverse != 0);
     if (ws->fused_finalize)
     {
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block

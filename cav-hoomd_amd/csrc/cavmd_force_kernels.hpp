@@ -275,13 +275,18 @@ __device__ __forceinline__ Scalars scalars_from_total(Accum acc, const PhotonRow
                                                       const DeviceParams& prm, bool want_energies)
 {
     Scalars sc;
+    // `want_energies` marks the one block that publishes cavmd_result: only it needs d_z, the all-particle dipole and the
+    // energies; every other block is on its way to the force map and needs Dq and F_L only.
     dd_norm(acc.hx, acc.lx);
     dd_norm(acc.hy, acc.ly);
-    dd_norm(acc.hz, acc.lz);
+    if (want_energies)
+        dd_norm(acc.hz, acc.lz);
     double dx = acc.hx, dy = acc.hy, dz = acc.hz;
-    // all particles, L-typed included (the photon normally has charge 0, so this usually equals d): the L-typed sum joins
-    // the double-double BEFORE the final rounding, so the low word is not thrown away when the two terms cancel
+    sc.dtot[0] = sc.dtot[1] = sc.dtot[2] = 0.0;
+    if (want_energies)
     {
+        // all particles, L-typed included (the photon normally has charge 0, so this usually equals d): the L-typed sum
+        // joins the double-double BEFORE the final rounding, so the low word is not thrown away when the two terms cancel
         double th = acc.hx, tl = acc.lx;
         dd_acc(th, tl, acc.sx);
         sc.dtot[0] = th + tl;

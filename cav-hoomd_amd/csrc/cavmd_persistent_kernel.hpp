@@ -61,29 +61,25 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 }
 
 // Wave 0 (all 64 lanes active): the Accum held by lane 0 -> record `rec` of `copies` consecutive copies of a slab of
-// `slab_records` records.  The 20 words are broadcast through SGPRs; one wave instruction stores three copies (60 lanes,
-// 160 contiguous bytes per copy).  Twenty separate 8-byte write-through stores from a single lane leave the CU one after
-// the other -- the guide's Pitfall 7 in miniature.
+// `slab_records` records.  Lane 0 spreads the 20 words over the lanes through `s_pub` (>= 20 words of LDS that only this
+// wave touches; a readfirstlane + select chain for the same job compiled to ~100 instructions, 0.3 us); one wave
+// instruction then stores three copies (60 lanes, 160 contiguous bytes per copy).  Twenty separate 8-byte write-through
+// stores from a single lane would leave the CU one after the other -- the guide's Pitfall 7 in miniature.
 __device__ __forceinline__ void publish_record(unsigned long long* slab, unsigned slab_records, unsigned copies, unsigned rec,
-                                               unsigned tag, const Accum& a)
+                                               unsigned tag, const Accum& a, unsigned* s_pub)
 {
-    const double d[kNumPartDoubles] = {a.hx, a.lx, a.hy, a.ly, a.hz, a.lz, a.sx, a.sy, a.sz};
     const unsigned lane = threadIdx.x;
-    const unsigned field = lane % kGranulesPerRecord, copy0 = lane / kGranulesPerRecord; // copy0 = 0, 1, 2 (3: idle lanes)
-    unsigned mine = 0;
-#pragma unroll
-    for (int i = 0; i < kNumPartDoubles; ++i)
+    if (lane == 0)
     {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(d[i]));
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(d[i]));
-        mine = field == 2u * i ? lo : mine;
-        mine = field == 2u * i + 1u ? hi : mine;
+        double* sd = reinterpret_cast<double*>(s_pub); // word 2 i = low half, 2 i + 1 = high half of double i
+        sd[0] = a.hx; sd[1] = a.lx; sd[2] = a.hy; sd[3] = a.ly; sd[4] = a.hz; sd[5] = a.lz;
+        sd[6] = a.sx; sd[7] = a.sy; sd[8] = a.sz;
+        s_pub[2 * kNumPartDoubles] = (unsigned)a.lmin;
+        s_pub[2 * kNumPartDoubles + 1] = (unsigned)a.lcnt;
     }
-    const unsigned lmin = (unsigned)__builtin_amdgcn_readfirstlane(a.lmin);
-    const unsigned lcnt = (unsigned)__builtin_amdgcn_readfirstlane(a.lcnt);
-    mine = field == 2u * kNumPartDoubles ? lmin : mine;
-    mine = field == 2u * kNumPartDoubles + 1u ? lcnt : mine;
-    const unsigned long long granule = ((unsigned long long)tag << 32) | mine;
+    // same wave: LDS operations complete in order, no barrier needed
+    const unsigned field = lane % kGranulesPerRecord, copy0 = lane / kGranulesPerRecord; // copy0 = 0, 1, 2 (3: idle lanes)
+    const unsigned long long granule = ((unsigned long long)tag << 32) | s_pub[field];
     for (unsigned c = copy0; c < copies && copy0 < 3; c += 3)
         __hip_atomic_store(slab + ((size_t)c * slab_records + rec) * kGranulesPerRecord + field, granule, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -246,15 +242,13 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     CAVMD_PSTAMP(2);
 
     // ---- hand-off: two-level all-reduce across the workgroups (wave 0; the other waves wait at the barrier below) ---------
-    __shared__ int s_failed;
-    __shared__ unsigned s_words[kGroup * kGranulesPerRecord];
+    __shared__ __attribute__((aligned(8))) unsigned s_words[kGroup * kGranulesPerRecord];
     unsigned long long* const block_slab = st.granules;
     unsigned long long* const group_slab = st.granules + (size_t)kMaxPersistGrid * kGranulesPerRecord;
-    Accum tot;
     if (tid < kWave)
     {
         bool ok = true;
-        publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc);
+        publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc, s_words);
         if ((b & (kGroup - 1)) == 0)
         {
             // first block of group b / 16: gather the group's records, fold, publish the group total
@@ -262,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             ok = gather_records(block_slab, b, min(G - b, (unsigned)kGroup), tag, s_words, o);
             t.merge(o);
             t = row_fold16(t);
-            publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t);
+            publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t, s_words);
         }
         CAVMD_PSTAMP(7);
         Accum o, t;
@@ -270,38 +264,34 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
                             tag, s_words, o)
              && ok;
         t.merge(o);
-        tot = row_fold16(t);
+        const Accum tot = row_fold16(t);
+        CAVMD_PSTAMP(3);
+        // The block that publishes cavmd_result (a system-scope release: ~0.6 us before its force stores can start) is the
+        // LAST block: it holds the fewest tiles (the ragged tail, or one tile less than the first blocks), so the detour is
+        // taken from its slack instead of from the kernel's critical path.
+        const bool publisher = (b == G - 1);
+        const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, publisher);
         if (tid == 0)
-            s_failed = !ok;
-    }
-    CAVMD_PSTAMP(3);
-    __syncthreads();
-    const bool any_failed = s_failed;
-    CAVMD_PSTAMP(4);
-    // The block that publishes cavmd_result (a system-scope release: ~0.6 us before its force stores can start) is the LAST
-    // block: it holds the fewest tiles (the ragged tail, or one tile less than the first blocks), so the detour is taken
-    // from its slack instead of from the kernel's critical path.
-    const bool publisher = (b == G - 1);
-    const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, publisher);
-    if (tid == 0)
-    {
-        s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
-        s_mi[0] = sc.photon;
-        s_mi[1] = sc.nL;
-        s_mi[2] = any_failed;
-        if (any_failed)
-            __hip_atomic_store(&res_host->sync_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (publisher)
         {
-            // every block has published, hence read the epoch: advance it for the next launch (0 is never a tag)
-            __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!any_failed)
+            s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
+            s_mi[0] = sc.photon;
+            s_mi[1] = sc.nL;
+            s_mi[2] = !ok;
+            if (!ok)
+                __hip_atomic_store(&res_host->sync_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (publisher)
             {
-                write_result(res, sc, N, G, sequence);
-                publish_to_host(res_host, sc, N, G, sequence);
+                // every block has published, hence read the epoch: advance it for the next launch (0 is never a tag)
+                __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ok)
+                {
+                    write_result(res, sc, N, G, sequence);
+                    publish_to_host(res_host, sc, N, G, sequence);
+                }
             }
         }
     }
+    CAVMD_PSTAMP(4);
     __syncthreads();
     CAVMD_PSTAMP(5);
     MapScalars m;

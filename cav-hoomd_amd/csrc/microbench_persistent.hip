@@ -173,12 +173,12 @@ int main(int argc, char** argv)
     for (int mode = 0; mode < 1; ++mode)
     {
         const unsigned g1 = grid(N, 256 * unroll, 1);
-        const char* names[8] = {"start", "phase1 done", "block tree done", "total in wave 0", "barrier passed",
-                                "scalars broadcast", "stores issued", "group level done"};
+        const char* names[8] = {"start", "phase1 done", "block tree done", "total in wave 0", "scalars in LDS",
+                                "barrier passed", "stores issued", "group level done"};
         std::vector<std::vector<double>> med(8), mx(8), mnv(8);
         for (int rep = 0; rep < 30; ++rep)
         {
-            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, true); // steady state: the stamps are those of the last launch
+            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, false); // steady state: the stamps are those of the last launch
             CHECK(hipDeviceSynchronize());
             std::vector<unsigned long long> h(4096 * kStampSlots);
             CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
@@ -207,7 +207,7 @@ int main(int argc, char** argv)
                 med[k].push_back(v[g1 / 2]); mx[k].push_back(v.back()); mnv[k].push_back(v.front());
             }
         }
-        printf("time line, single launch (balanced shares), grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
+        printf("time line, single launch, grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
                g1);
         for (int k : {0, 1, 2, 7, 3, 4, 5, 6})
         {
