@@ -42,6 +42,7 @@ constexpr size_t kChargeTemporalMaxN = 25000000; // charges stay temporal while 
                                                  // 6e6 and 1e7, -5 % at 2e7, tie at 5e7 (profiles/r02/ab_two_launch_knobs.txt)
 constexpr int kPersistBlock = 256;
 constexpr size_t kPersistMaxLds = 156 * 1024; // dynamic LDS of the single-launch kernel (charges of a block's tiles); 160 KiB per CU
+constexpr size_t kPersistSharedLds = 76 * 1024; // default ceiling: two such blocks fit on one CU (two concurrent grids stay resident)
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
 static_assert(sizeof(cavmd_int3) == 12, "int3 layout");
@@ -486,7 +487,11 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         const bool resident = g1 <= kMaxPersistGrid && ws->reduce_blocks_per_cu <= 4;
         // auto: only while every tile of a block fits in LDS.  With overflow tiles the second phase (one block per CU, loads
         // and stores of a tile back to back) is latency-bound: 170 us against 138 us for two launches at N = 1e7.
-        if (resident && (ws->persistent > 0 || (ws->persistent < 0 && slots <= cap_slots && persistent_auto(N))))
+        // Nor by default beyond half a CU's LDS per block (N >~ 2.4e6): two such grids from different streams or processes
+        // could then not be resident side by side, and two half-resident grids would wait for each other until their
+        // bounded spins give up (a loud CAVMD_ERR_SYNC_TIMEOUT, but a failure).  persistent = 1 lifts both limits.
+        if (resident && (ws->persistent > 0
+                         || (ws->persistent < 0 && slots <= cap_slots && lds <= kPersistSharedLds && persistent_auto(N))))
         {
             ws->sequence += 1;
             const AosInputT<2> inx {in.pos2, in.charge, in.image};

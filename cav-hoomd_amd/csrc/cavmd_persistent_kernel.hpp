@@ -248,6 +248,9 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     if (tid < kWave)
     {
         bool ok = true;
+#ifdef CAVMD_FAULT_SILENT_BLOCK // microbench only: this block never publishes, as if it were not resident
+        if (b != CAVMD_FAULT_SILENT_BLOCK)
+#endif
         publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc, s_words);
         if ((b & (kGroup - 1)) == 0)
         {
@@ -256,7 +259,10 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             ok = gather_records(block_slab, b, min(G - b, (unsigned)kGroup), tag, s_words, o);
             t.merge(o);
             t = row_fold16(t);
-            publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t, s_words);
+            // (a group whose gather timed out publishes nothing: every block then times out on the group totals and the
+            // whole evaluation fails loudly, instead of a wrong total spreading with a valid tag)
+            if (ok)
+                publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t, s_words);
         }
         CAVMD_PSTAMP(7);
         Accum o, t;

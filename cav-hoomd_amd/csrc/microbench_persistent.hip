@@ -114,6 +114,33 @@ int main(int argc, char** argv)
 #define ALLOW(UNR, NTS) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
     ALLOW(1, false); ALLOW(1, true); ALLOW(2, false); ALLOW(2, true);
 
+#ifdef CAVMD_FAULT_SILENT_BLOCK
+    {
+        // fault injection: one launch in which a block stays silent.  Expected: the kernel ends after its bounded spins
+        // (seconds, not forever), sync_error is raised, every force entry is NaN.
+        std::vector<double> h_f(4 * N, 0.0);
+        CHECK(hipMemset(d_hres, 0, sizeof(HostResult)));
+        hipEvent_t a, b2;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b2));
+        const unsigned g1 = grid(N, 256 * unroll, 1);
+        const size_t tile = 256 * unroll;
+        const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        CHECK(hipEventRecord(a, st));
+        if (unroll == 2)
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 2, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+        else
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 1, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+        CHECK(hipEventRecord(b2, st));
+        CHECK(hipEventSynchronize(b2));
+        float ms; CHECK(hipEventElapsedTime(&ms, a, b2));
+        HostResult hr; CHECK(hipMemcpy(&hr, d_hres, sizeof(hr), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_f.data(), d_frc[0], 32 * N, hipMemcpyDeviceToHost));
+        size_t nan = 0; for (double v : h_f) nan += (v != v);
+        printf("fault injection (block %d silent, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu of %zu\n",
+               CAVMD_FAULT_SILENT_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, h_f.size());
+        return (hr.sync_error == 1 && nan == h_f.size() && hr.ready == 0) ? 0 : 1;
+    }
+#endif
     std::vector<Variant> V;
     // the product's two-launch sequence
     V.push_back({"two launches (K1 nt1 bpc1 | fused map u4 bpc2)", [&](int f) {

@@ -279,7 +279,11 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "small_system_max_n"   0..2^20 at or below this N one single-block launch does the whole evaluation (0 = never)
  *   "persistent"           -1..1   ONE launch per evaluation (reduction, in-launch all-reduce of the partials, force map from
  *                                  charges kept in LDS): 1 whenever the grid is <= 256 blocks, 0 never (two launches),
- *                                  -1 auto (where it measured faster: everywhere above small_system_max_n).
+ *                                  -1 auto: while a block's charges take at most half a CU's LDS (N <~ 2.4e6), so that two
+ *                                  concurrent grids (other streams, other processes on the same GPU) can both be resident.
+ *                                  The kernel's workgroups wait for each other inside the launch: they must all be
+ *                                  resident together; every wait is bounded and a give-up is reported as
+ *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces.
  *   "persistent_balanced"  -1..1   partition of the particles over the blocks of the single-launch kernel: 0 tiles dealt
  *                                  round-robin (the two-launch path's partition: then also its bits), 1 contiguous equal
  *                                  shares, -1 auto
