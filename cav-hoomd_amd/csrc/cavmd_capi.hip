@@ -69,7 +69,7 @@ struct cavmd_workspace
     // Defaults from interleaved A/B runs on MI355X (csrc/microbench.hip; profiles/r01/microbench_*.txt):
     int reduce_blocks_per_cu = 1; // <= 256 partials: the fused force map folds them with one load per thread
     int map_blocks_per_cu = 2;    // every fused block re-folds the partials, so few, long-lived blocks
-    int map_nt_store = -1;        // -1 auto (non-temporal from kNtStoreMinN particles up), 0 plain, 1 non-temporal
+    int map_nt_store = -1;        // -1 auto (non-temporal from kNtStoreMinN particles up), 0 plain, 1 non-temporal, 2 write-through
     int reduce_nt_load = -1;      // -1 auto, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     int map_reverse = -1;         // -1 auto, 1: the force map walks its tiles last-to-first, 0: first-to-last
@@ -225,10 +225,12 @@ hipError_t allow_large_lds()
     if (e == hipSuccess)                                                                                        \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, UNR, NTS>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
-        CAVMD_ALLOW(1, false)
-        CAVMD_ALLOW(1, true)
-        CAVMD_ALLOW(2, false)
-        CAVMD_ALLOW(2, true)
+        CAVMD_ALLOW(1, 0)
+        CAVMD_ALLOW(1, 1)
+        CAVMD_ALLOW(1, 2)
+        CAVMD_ALLOW(2, 0)
+        CAVMD_ALLOW(2, 1)
+        CAVMD_ALLOW(2, 2)
 #undef CAVMD_ALLOW
         return e;
     }();
@@ -463,7 +465,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     // Force stores bypass the caches for all but small N: the array is consumed much later (by the integrator, after
     // every other force of the step), and not leaving 32 N dirty bytes behind shortens this kernel's drain and spares
     // the next reduction the evictions (measured on whole evaluations, profiles/r01/microbench_*.txt).
-    const bool nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN) : (ws->map_nt_store != 0);
+    const int nt_store = ws->map_nt_store < 0 ? (N >= kNtStoreMinN ? 1 : 0) : ws->map_nt_store;
 
     // ---- ONE launch (cavmd_persistent_kernel.hpp): the same grid as launch 1 below; with the strided partition also the
     // same tiles, hence the same partials and (same fold) the same bits as two launches.  Needs the whole grid resident at
@@ -501,17 +503,21 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
                        dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2, (unsigned)lds_slots, balanced);
             if (unroll == 2)
             {
-                if (nt_store)
-                    CAVMD_LAUNCH_PERSIST(2, true)
+                if (nt_store == 2)
+                    CAVMD_LAUNCH_PERSIST(2, 2)
+                else if (nt_store == 1)
+                    CAVMD_LAUNCH_PERSIST(2, 1)
                 else
-                    CAVMD_LAUNCH_PERSIST(2, false)
+                    CAVMD_LAUNCH_PERSIST(2, 0)
             }
             else
             {
-                if (nt_store)
-                    CAVMD_LAUNCH_PERSIST(1, true)
+                if (nt_store == 2)
+                    CAVMD_LAUNCH_PERSIST(1, 2)
+                else if (nt_store == 1)
+                    CAVMD_LAUNCH_PERSIST(1, 1)
                 else
-                    CAVMD_LAUNCH_PERSIST(1, false)
+                    CAVMD_LAUNCH_PERSIST(1, 0)
             }
 #undef CAVMD_LAUNCH_PERSIST
             if (st != CAVMD_OK)
@@ -562,11 +568,14 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     if (ws->fused_finalize)
     {
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
-        if (nt_store)
-            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, true>, g2, kMapBlock, in, n, g1, Lx, Ly,
+        if (nt_store == 2)
+            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 2>, g2, kMapBlock, in, n, g1, Lx, Ly,
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
+        else if (nt_store == 1)
+            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 1>, g2, kMapBlock, in, n, g1, Lx, Ly,
                            Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
         else
-            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, false>, g2, kMapBlock, in, n, g1, Lx, Ly,
+            st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 0>, g2, kMapBlock, in, n, g1, Lx, Ly,
                            Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
     }
     else
@@ -1089,7 +1098,7 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
     }
     if (!strcmp(name, "map_nt_store"))
     {
-        if (value < -1 || value > 1)
+        if (value < -1 || value > 2)
             return CAVMD_ERR_INVALID_VALUE;
         ws->map_nt_store = value;
         return CAVMD_OK;

@@ -497,10 +497,15 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(Input in, unsigned N, u
 }
 
 // ---- force map, HOOMD AoS force array written as dense 16-byte chunks ------------------------------------------
-template <bool NT>
+// Store policy of the force array: 0 plain (write-back), 1 non-temporal, 2 write-through (sc1: the bytes leave the XCD's L2
+// while the kernel runs instead of at its end-of-kernel release; after 320 MB of non-temporal stores at N = 1e7 the next
+// kernel in the stream started 8.7 us late).
+template <int NT>
 __device__ __forceinline__ void store_chunk(v2d* p, v2d v)
 {
-    if (NT)
+    if (NT == 2)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else if (NT == 1)
         __builtin_nontemporal_store(v, p);
     else
         *p = v;
@@ -517,7 +522,7 @@ struct MapScalars
 // Even chunk = (Fx, Fy) = ((-g c) Dq_x, (-g c) Dq_y), odd chunk = (Fz, w) = (0, 0); the photon's chunks carry F_L.
 // PRE: the caller has already loaded the charges of this block's first full tile into c_first (issued before its
 // prologue so that their latency is hidden behind it).
-template <int BLOCK, int UNROLL, bool NT, bool PRE>
+template <int BLOCK, int UNROLL, int NT, bool PRE>
 __device__ __forceinline__ void force_map_body(const MapScalars m, const double* __restrict__ charge,
                                                const v2d* __restrict__ pos2, unsigned N, double g, int L_typeid,
                                                v2d* __restrict__ force2, const double (&c_first)[UNROLL],
@@ -610,7 +615,7 @@ __device__ __forceinline__ void force_map_body(const MapScalars m, const double*
 }
 
 // three-launch path: scalars come from the result block the finalize kernel wrote
-template <int BLOCK, int UNROLL, bool NT>
+template <int BLOCK, int UNROLL, int NT>
 __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __restrict__ charge,
                                                               const v2d* __restrict__ pos2, // only read if several L-typed
                                                               unsigned N, double g, int L_typeid,
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_kernel(const double* __re
 
 // two-launch path: every block folds the partials itself (same fixed order -> same bits in every block), block 0
 // publishes the result block; no separate finalize launch and no inter-workgroup hand-off inside the launch.
-template <int BLOCK, int UNROLL, bool NT>
+template <int BLOCK, int UNROLL, int NT>
 __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in, unsigned N, unsigned nparts, double Lx,
                                                                     double Ly, double Lz, DeviceParams prm, int L_typeid,
                                                                     Partials part, uint64_t sequence,

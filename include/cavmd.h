@@ -272,7 +272,8 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
 /* Launch knobs (for A/B measurements; the defaults are the measured best on MI355X).  name is one of
  *   "reduce_blocks_per_cu" 1..16   grid of the reduction = min(tiles, CUs * value); also the number of partials
  *   "map_blocks_per_cu"    1..16   grid of the force map
- *   "map_nt_store"         -1..1   -1 auto by N, 0 plain, 1 non-temporal force stores
+ *   "map_nt_store"         -1..2   force stores: -1 auto by N, 0 plain, 1 non-temporal, 2 write-through (sc1; measured slower
+ *                                  at every size, profiles/r02/ab_store_policy.txt)
  *   "reduce_nt_load"       -1..2   -1 auto by N, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
  *   "map_reverse"          -1..1   -1 auto by N, 1: the force map walks its tiles last-to-first, 0: first-to-last
