@@ -4,8 +4,8 @@
 // (src/CavityForceComputeGPU.cc:102-253) and kernel::gpu_compute_cavity_force
 // (src/CavityForceComputeGPU.cu:507-617).  Where the reference does 4 memsets, 1 H2D and 2 blocking
 // D2H copies, a device synchronise and a host scan of the position array per step, this enqueues
-// two kernels on the caller's stream and returns; the energies reach the host through a block of mapped pinned
-// memory that cavmd_energies polls (no copy, no stream synchronisation).
+// one kernel (two above ~2.4e6 particles) on the caller's stream and returns; the energies reach the host through a
+// block of mapped pinned memory that cavmd_energies polls (no copy, no stream synchronisation).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 

@@ -19,7 +19,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, os.path.join(ROOT, "cav-hoomd_amd"))
 
 import cavitymd  # noqa: E402
-from cavitymd import PhysicalConstants, observables, synthetic  # noqa: E402
+from cavitymd import PhysicalConstants, observables, synthetic, thermostats  # noqa: E402
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
     vel4 = torch.from_numpy(np.concatenate([np.zeros((n, 3)), mass[:, None]], axis=1)).cuda()   # HOOMD Scalar4 velocity
 
     for step in range(5):
-        force.compute(step)                                   # two kernel launches, asynchronous
+        force.compute(step)                                   # one kernel launch, asynchronous
         print(f"step {step}: E_harmonic={force.harmonic_energy:.6e} E_coupling={force.coupling_energy:.6e} "
               f"E_dipole_self={force.dipole_self_energy:.6e} total={force.energy:.6e}")
         pdata.getPositions()[:, :3] += 1e-3 * torch.randn((n, 3), dtype=torch.float64, device="cuda")
@@ -49,6 +49,16 @@ def main():
     print("sum |F|/m =", S, "-> dt =", observables.adaptive_timestep(1e-3, S))
     print("|rho(k)| for the first 3 wavevectors:", np.abs(field.compute()[:3]))
     print("forces on the first 2 particles:\n", force.forces[:2])
+
+    # the Bussi reservoir thermostat of the reference's driver (examples/05_advanced_run.py:780-804), applied to the
+    # molecular group; HOOMD's integration method would call it once per step and rescale the velocities itself
+    vel4[:, :3] = 1e-3 * torch.randn((n, 3), dtype=torch.float64, device="cuda")
+    bussi = thermostats.BussiReservoir(kT=PhysicalConstants.KB_HARTREE_PER_K * 100.0, tau=5.0)
+    bussi.attach(n, members=np.arange(n - 1, dtype=np.uint32))
+    rng = np.random.default_rng(0)
+    for step in range(3):
+        alpha, _ = bussi.step(step, 1.0, vel4, translational_dof=3.0 * (n - 1) - 3.0, rng=rng)
+        print(f"thermostat step {step}: alpha={alpha:.6f} reservoir={bussi.total_reservoir_energy:.6e}")
 
 
 if __name__ == "__main__":
