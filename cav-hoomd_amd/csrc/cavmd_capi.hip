@@ -740,7 +740,10 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
     }
     if (__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
     {
+        // The evaluation failed loudly (NaN forces).  The result block still holds the PREVIOUS evaluation: invalidate it, so
+        // that a second read reports "nothing computed" instead of handing that out as if it were current.
         __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
+        ws->computed = false;
         return CAVMD_ERR_SYNC_TIMEOUT;
     }
     memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
