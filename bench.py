@@ -47,21 +47,34 @@ def launch_ranks(n_ranks, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    import tempfile
     procs = []
+    out0_file = tempfile.TemporaryFile(mode="w+")   # rank 0's stdout: holds the JSON line, relayed when all ranks are done
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for pr in procs[1:]:
-        try:
-            codes.append(pr.wait(timeout=600 if codes[0] == 0 else 30))
-        except subprocess.TimeoutExpired:
-            pr.kill()                    # exactly the child this parent started
-            codes.append(pr.wait())
+                                      stdout=out0_file if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    # Wait for all ranks; if one fails, the others would sit in a collective until its time-out: end them (exactly the
+    # children started above) after a short grace period instead.
+    codes = [None] * n_ranks
+    failed_at = None
+    while any(c is None for c in codes):
+        for k, pr in enumerate(procs):
+            if codes[k] is None:
+                codes[k] = pr.poll()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 20.0:
+            for k, pr in enumerate(procs):
+                if codes[k] is None:
+                    pr.kill()
+                    codes[k] = pr.wait()
+        time.sleep(0.05)
+    out0_file.seek(0)
+    out0 = out0_file.read()
+    out0_file.close()
     lines = out0.splitlines()
     json_at = max((k for k, ln in enumerate(lines) if ln.startswith("{") and '"metric"' in ln), default=None)
     for k, ln in enumerate(lines):
@@ -104,7 +117,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-molecular", type=int, default=1_000_000)
     ap.add_argument("--frames", type=int, default=0, help="trajectory frames in the ring (0 = enough to exceed 2x the Infinity Cache)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget for the cpu_baseline leg (split over the -O2 and -O3 builds)")
     ap.add_argument("--no-extras", action="store_true", help="skip the 1e5 / 1e7 / cache-hot side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -249,7 +262,7 @@ def cpu_baseline(cfg, budget_s):
         p = ref.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
         args = (pos4, cfg["charge"], cfg["image"], cfg["box"], cfg["L_typeid"], p)
         t1 = ref.time_evaluations(*args, 2) / 2          # warm-up + estimate
-        iters = int(max(3, min(2000, (budget_s / 2) / max(t1, 1e-9))))
+        iters = int(max(3, min(5000, (budget_s / 2) / max(t1, 1e-9))))
         t = ref.time_evaluations(*args, iters)
         out[opt] = {"evals_per_s": iters / t, "iters": iters, "seconds": t}
     best = "O2"
