@@ -74,6 +74,7 @@ struct cavmd_workspace
     int fused_finalize = 1;       // 1: two launches (finalize folded into the force map), 0: three launches
     int map_reverse = -1;         // -1 auto, 1: the force map walks its tiles last-to-first, 0: first-to-last
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
+    int reduce_unroll = -1;       // particles per lane and tile of the reduction: -1 auto, 1 or 2
     int persistent = -1;          // -1 auto, 0 never, 1 whenever the grid is <= 256 blocks: ONE launch per evaluation
     int persistent_balanced = -1; // partition of the particles over the blocks of the single-launch kernel: -1 auto, 0 tiles
                                   // dealt round-robin (the two-launch path's partition), 1 contiguous, equal shares
@@ -455,11 +456,14 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     }
 
     // ---- launch 1: per-block partial sums + photon search
-    // Tile depth: 2 particles per lane (512 per block; 8 loads in flight per lane); 1 for very small N so that a
-    // useful share of the CUs takes part (measured: 2 still wins at N = 1e5, where it fills 195 CUs).
+    // Tile depth: 2 particles per lane (512 per block; 8 loads in flight per lane); 1 while that leaves at most about one
+    // tile per CU (re-measured with the single-launch kernel: 1 wins by 9 % at N = 5e4 and 4 % at 1.3e5, ties at 1e5,
+    // loses by 6 % from 2e5 up: profiles/r02/ab_reduce_unroll.txt).
     int unroll = kReduceUnroll;
-    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu / 4)
+    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu * 5 / 4)
         unroll >>= 1;
+    if (ws->reduce_unroll == 1 || ws->reduce_unroll == 2)
+        unroll = ws->reduce_unroll;
     const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
     v2d* force2 = reinterpret_cast<v2d*>(d_force);
     // Force stores bypass the caches for all but small N: the array is consumed much later (by the integrator, after
@@ -665,8 +669,10 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
 
     // same tile-depth rule as cavmd_compute_hoomd, so that both layouts share one summation tree (and give equal bits)
     int unroll = kReduceUnroll;
-    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu / 4)
+    while (unroll > 1 && N / ((size_t)kReduceBlock * unroll) < (size_t)ws->num_cu * 5 / 4)
         unroll >>= 1;
+    if (ws->reduce_unroll == 1 || ws->reduce_unroll == 2)
+        unroll = ws->reduce_unroll;
     const unsigned g1 = grid_for(N, kReduceBlock * unroll, ws->num_cu, ws->reduce_blocks_per_cu);
     int st;
     if (unroll == 2)
@@ -1141,6 +1147,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->persistent = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "reduce_unroll"))
+    {
+        if (value != -1 && value != 1 && value != 2)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->reduce_unroll = value;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "persistent_balanced"))
     {
         if (value < -1 || value > 1)
@@ -1171,6 +1184,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->small_system_max_n;
     else if (!strcmp(name, "persistent"))
         *value = ws->persistent;
+    else if (!strcmp(name, "reduce_unroll"))
+        *value = ws->reduce_unroll;
     else if (!strcmp(name, "persistent_balanced"))
         *value = ws->persistent_balanced;
     else

@@ -108,7 +108,7 @@ int main(int argc, char** argv)
         size_t tiles = (items + tile - 1) / tile; size_t cap = (size_t)CU * bpc; return (unsigned)std::max<size_t>(1, std::min(tiles, cap)); };
 
     int unroll = 2;
-    while (unroll > 1 && N / ((size_t)256 * unroll) < (size_t)CU / 4)
+    while (unroll > 1 && N / ((size_t)256 * unroll) < (size_t)CU * 5 / 4)
         unroll >>= 1;
     const bool nts = N >= 200000;
 #define ALLOW(UNR, NTS) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
