@@ -343,6 +343,36 @@ def density_field_measurement(cfg, device, n_k=50, kmag=1.0, steps=20, warmup=3)
             "note": "fp64 transcendental bound: N*n_k sincos per call; positions are only 32 N bytes"}
 
 
+def thermostat_measurement(n, device, steps=50, warmup=5):
+    """Row f4 side measurement: one Bussi reservoir step = group kinetic energy on the GPU (32 N bytes read, result to the
+    host: the scalar rule needs it), host arithmetic, velocity rescale (64 N bytes)."""
+    from cavitymd import thermostats
+    rng = np.random.default_rng(0)
+    vel = np.empty((n, 4))
+    vel[:, :3] = rng.normal(0, 1e-3, (n, 3))
+    vel[:, 3] = 2.7e4
+    dvel = torch.from_numpy(vel).to(device)
+    th = thermostats.BussiReservoir(kT=3.167e-4, tau=5.0)
+    th.attach(n, members=None, device=device)
+    dof = 3.0 * n - 3.0
+    var = [0.3, (dof - 1) / 2, 0.0, 0.0]
+    for _ in range(warmup):
+        th.step(0, 1.0, dvel, dof, variates=var)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        th.kinetic_energy(dvel)
+    t_ke = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for s in range(steps):
+        th.step(s, 1.0, dvel, dof, variates=var)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    return {"N": n, "kinetic_energy_us": 1e6 * t_ke, "kinetic_energy_GBps": 32 * n / t_ke / 1e9, "full_step_us": 1e6 * t_step,
+            "note": "KE = one kernel, the number reaches the host through a mapped flag (the scalar rule needs it); a step adds the "
+                    "asynchronous rescale kernel"}
+
+
 def main():
     args = parse_args()
     ctx = replicas.init_from_env(prefer_gpu=True)
@@ -414,6 +444,7 @@ def main():
             # the reference's own production size (examples/init-0.gsd stand-in): one single-block launch per evaluation
             extras["config1_N501"] = side_measurement(synthetic.config1(), ctx.device, 1, 2000, 100)
             extras["density_field_1e6_50k"] = density_field_measurement(cfg, ctx.device)
+            extras["bussi_thermostat_step_1e6"] = thermostat_measurement(n, ctx.device)
             extras["1e6_energy_poll_every_step"] = energy_poll_measurement(cfg, ctx.device, spec["frames"], spec["steps"],
                                                                            spec["warmup"])
             line["extras"] = extras

@@ -103,7 +103,10 @@ struct cavmd_workspace
     double* d_mode = nullptr;
     double* h_mode = nullptr; // pinned
     double* d_fm_part = nullptr; // [2][max_parts] + 1 result
-    double* h_fm = nullptr;      // pinned
+    HostScalar* h_fm = nullptr;     // pinned, mapped, coherent: the scalar reductions publish here, the host spins on `ready`
+    HostScalar* h_fm_dev = nullptr; // device-side address of h_fm
+    uint64_t fm_sequence = 0;
+    unsigned* d_fm_ticket = nullptr; // ticket counter of the one-launch scalar reductions (reset by the folding block)
 };
 
 namespace
@@ -213,6 +216,43 @@ unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_c
     size_t cap = (size_t)num_cu * (size_t)blocks_per_cu;
     size_t g = tiles < cap ? tiles : cap;
     return (unsigned)(g ? g : 1);
+}
+
+// Scratch of the scalar reductions (sum |F| / m, kinetic energy): partials + the host-visible scalar.
+int ensure_scalar_scratch(cavmd_workspace* ws)
+{
+    if (ws->d_fm_part)
+        return CAVMD_OK;
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_part, sizeof(double) * (2 * (size_t)ws->max_parts + 1)));
+    CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_fm, sizeof(HostScalar), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ws->h_fm, 0, sizeof(HostScalar));
+    CAVMD_HIP_TRY(hipHostGetDevicePointer((void**)&ws->h_fm_dev, ws->h_fm, 0));
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_ticket, 128));
+    CAVMD_HIP_TRY(hipMemset(ws->d_fm_ticket, 0, 128));
+    return CAVMD_OK;
+}
+
+// Wait for the scalar the fold kernel publishes (flag in mapped host memory; the stream going idle ends the wait too, e.g.
+// after a failed launch) -- about a PCIe write after the kernel has it, instead of a copy plus a stream synchronisation.
+int wait_scalar(cavmd_workspace* ws, hipStream_t stream, double* out)
+{
+    const uint64_t want = ws->fm_sequence;
+    for (;;)
+    {
+        if (__atomic_load_n(&ws->h_fm->ready, __ATOMIC_ACQUIRE) == want)
+            break;
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess)
+        {
+            if (__atomic_load_n(&ws->h_fm->ready, __ATOMIC_ACQUIRE) != want)
+                return (int)hipErrorLaunchFailure;
+            break;
+        }
+        if (q != hipErrorNotReady)
+            return (int)q;
+    }
+    *out = ws->h_fm->value;
+    return CAVMD_OK;
 }
 
 // The single-launch kernel keeps the charges of a block's tiles in dynamic LDS (up to kPersistMaxLds); HIP wants the
@@ -405,6 +445,8 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipFree(ws->d_fm_part);
     if (ws->h_fm)
         (void)hipHostFree(ws->h_fm);
+    if (ws->d_fm_ticket)
+        (void)hipFree(ws->d_fm_ticket);
     delete ws;
     return CAVMD_OK;
 }
@@ -889,24 +931,22 @@ int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream_, size_t N, const cav
     }
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    if (!ws->d_fm_part)
     {
-        CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_part, sizeof(double) * (2 * (size_t)ws->max_parts + 1)));
-        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_fm, sizeof(double), hipHostMallocDefault));
+        const int st0 = ensure_scalar_scratch(ws);
+        if (st0 != CAVMD_OK)
+            return st0;
     }
     constexpr int kBlock = 256, kUnroll = 4;
-    const unsigned g = grid_for(N, kBlock * kUnroll, ws->num_cu, 4);
+    // one block per CU: every block draws a ticket from ONE counter (~12 ns each, serialised at the memory side); with four
+    // blocks per CU the 1024 tickets alone took 12 us
+    const unsigned g = grid_for(N, kBlock * kUnroll, ws->num_cu, 1);
     double* d_out = ws->d_fm_part + 2 * (size_t)ws->max_parts;
-    hipLaunchKernelGGL((force_mass_partials_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+    ws->fm_sequence += 1;
+    hipLaunchKernelGGL((force_mass_fused_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
                        reinterpret_cast<const v2d*>(d_net_force), reinterpret_cast<const v2d*>(d_vel), (unsigned)N,
-                       ws->d_fm_part);
+                       ws->d_fm_part, ws->d_fm_ticket, d_out, ws->h_fm_dev, ws->fm_sequence);
     CAVMD_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((force_mass_fold_kernel<kBlock>), dim3(1), dim3(kBlock), 0, stream, ws->d_fm_part, g, d_out);
-    CAVMD_HIP_TRY(hipGetLastError());
-    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_fm, d_out, sizeof(double), hipMemcpyDeviceToHost, stream));
-    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
-    *out = *ws->h_fm;
-    return CAVMD_OK;
+    return wait_scalar(ws, stream, out);
 }
 
 int cavmd_kinetic_energy(cavmd_workspace* ws, void* stream_, const cavmd_double4* d_vel, const uint32_t* d_members,
@@ -923,23 +963,20 @@ int cavmd_kinetic_energy(cavmd_workspace* ws, void* stream_, const cavmd_double4
     }
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    if (!ws->d_fm_part)
     {
-        CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_fm_part, sizeof(double) * (2 * (size_t)ws->max_parts + 1)));
-        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_fm, sizeof(double), hipHostMallocDefault));
+        const int st0 = ensure_scalar_scratch(ws);
+        if (st0 != CAVMD_OK)
+            return st0;
     }
     constexpr int kBlock = 256, kUnroll = 4;
-    const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 4);
+    const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 1); // one ticket per CU, see cavmd_force_mass_sum
     double* d_out = ws->d_fm_part + 2 * (size_t)ws->max_parts;
-    hipLaunchKernelGGL((kinetic_partials_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part);
+    ws->fm_sequence += 1;
+    hipLaunchKernelGGL((kinetic_fused_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, ws->d_fm_ticket,
+                       d_out, ws->h_fm_dev, ws->fm_sequence);
     CAVMD_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((kinetic_fold_kernel<kBlock>), dim3(1), dim3(kBlock), 0, stream, ws->d_fm_part, g, d_out);
-    CAVMD_HIP_TRY(hipGetLastError());
-    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_fm, d_out, sizeof(double), hipMemcpyDeviceToHost, stream));
-    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
-    *out = *ws->h_fm;
-    return CAVMD_OK;
+    return wait_scalar(ws, stream, out);
 }
 
 int cavmd_scale_velocities(cavmd_workspace* ws, void* stream_, cavmd_double4* d_vel, const uint32_t* d_members,

@@ -215,7 +215,9 @@ CAVMD_API int cavmd_cavity_mode(cavmd_workspace* ws, void* stream, const cavmd_d
 
 /* S = sum_i |F_i| / m_i over a Scalar4 net-force array and HOOMD's Scalar4 velocity array (mass in .w): the reduction
  * AdaptiveTimestepUpdater performs on the host every step to set dt = sqrt(tol / S) (src/cavitymd/simulation.py:66-92).
- * Enqueues two kernels and an 8-byte copy on `stream` and waits for them (the caller needs the number to set dt). */
+ * Enqueues ONE kernel on `stream` (the block that finishes last folds the partials in a fixed order and hands the number to
+ * the host through mapped pinned memory); this call spins on its flag: no copy, no stream synchronisation (the caller needs
+ * the number to set dt). */
 CAVMD_API int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream, size_t N, const cavmd_double4* d_net_force,
                                    const cavmd_double4* d_vel, double* out);
 
@@ -223,7 +225,8 @@ CAVMD_API int cavmd_force_mass_sum(cavmd_workspace* ws, void* stream, size_t N, 
 /* Translational kinetic energy 1/2 sum_j m_j v_j.v_j of a particle group: what BussiReservoirThermostat reads from
  * ComputeThermo (src/BussiReservoirThermostat.h:49-54).  d_vel is HOOMD's Scalar4 velocity array (mass in .w);
  * d_members is a DEVICE array of n_members particle indices (HOOMD's ParticleGroup index list) or NULL for the particles
- * 0 .. n_members-1.  Enqueues two kernels and an 8-byte copy on `stream` and waits for them. */
+ * 0 .. n_members-1.  Enqueues ONE kernel on `stream` and spins on its host-visible flag (no copy, no stream
+ * synchronisation). */
 CAVMD_API int cavmd_kinetic_energy(cavmd_workspace* ws, void* stream, const cavmd_double4* d_vel, const uint32_t* d_members,
                                    size_t n_members, double* out);
 /* v_j.xyz *= alpha for the members of the group: what HOOMD's integration method does with the factor the thermostat
