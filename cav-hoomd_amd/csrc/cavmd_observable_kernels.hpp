@@ -353,45 +353,6 @@ __device__ __forceinline__ bool fold_by_last_block(DD& acc, double* __restrict__
 }
 
 template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void force_mass_partials_kernel(const v2d* __restrict__ force2,
-                                                                    const v2d* __restrict__ vel2, unsigned N,
-                                                                    double* __restrict__ part /* [2][gridDim] */)
-{
-    constexpr unsigned TILE = BLOCK * UNROLL;
-    DD acc {0.0, 0.0};
-    const unsigned tiles = (N + TILE - 1) / TILE;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
-    {
-        const size_t base = (size_t)t * TILE + threadIdx.x;
-        v2d fxy[UNROLL], fzw[UNROLL], vzw[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            const size_t i = base + (size_t)u * BLOCK;
-            const bool ok = i < N;
-            const v2d zero = {0.0, 0.0}, one = {0.0, 1.0};
-            fxy[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i) : zero;
-            fzw[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i + 1) : zero;
-            vzw[u] = ok ? __builtin_nontemporal_load(vel2 + 2 * i + 1) : one;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            const double n2 = (fxy[u].x * fxy[u].x + fxy[u].y * fxy[u].y) + fzw[u].x * fzw[u].x;
-            dd_acc(acc.hi, acc.lo, sqrt(n2) / vzw[u].y); // |F_i| / m_i; padding lanes add 0 / 1
-        }
-    }
-    acc = block_reduce_dd1<BLOCK>(acc);
-    if (threadIdx.x == 0)
-    {
-        part[blockIdx.x] = acc.hi;
-        part[gridDim.x + blockIdx.x] = acc.lo;
-    }
-}
-
-// one-launch variant: partials + fold by the last block + hand-off to the host
-template <int BLOCK, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void force_mass_fused_kernel(const v2d* __restrict__ force2, const v2d* __restrict__ vel2,
                                                                  unsigned N, double* __restrict__ part,
                                                                  unsigned* __restrict__ ticket, double* __restrict__ out,
@@ -430,21 +391,6 @@ __global__ __launch_bounds__(BLOCK) void force_mass_fused_kernel(const v2d* __re
     }
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void force_mass_fold_kernel(const double* __restrict__ part, unsigned nparts,
-                                                                double* __restrict__ out, HostScalar* __restrict__ host,
-                                                                uint64_t sequence)
-{
-    DD acc {0.0, 0.0};
-    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
-        dd_merge(acc.hi, acc.lo, part[p], part[nparts + p]);
-    acc = block_reduce_dd1<BLOCK>(acc);
-    if (threadIdx.x == 0)
-    {
-        out[0] = acc.hi + acc.lo;
-        publish_scalar(host, acc.hi + acc.lo, sequence);
-    }
-}
 } // namespace cavmd
 
 // =====================================================================================================================
@@ -458,42 +404,6 @@ __global__ __launch_bounds__(BLOCK) void force_mass_fold_kernel(const double* __
 // =====================================================================================================================
 namespace cavmd
 {
-template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void kinetic_partials_kernel(const v2d* __restrict__ vel2,
-                                                                 const unsigned* __restrict__ members, unsigned n,
-                                                                 double* __restrict__ part /* [2][gridDim] */)
-{
-    constexpr unsigned TILE = BLOCK * UNROLL;
-    DD acc {0.0, 0.0};
-    const unsigned tiles = (n + TILE - 1) / TILE;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
-    {
-        const size_t base = (size_t)t * TILE + threadIdx.x;
-        v2d vxy[UNROLL], vzw[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            const size_t k = base + (size_t)u * BLOCK;
-            const bool ok = k < n;
-            const v2d zero = {0.0, 0.0};
-            const size_t j = ok ? (members ? (size_t)members[k] : k) : 0;
-            vxy[u] = ok ? vel2[2 * j] : zero;
-            vzw[u] = ok ? vel2[2 * j + 1] : zero; // padding lanes: mass 0 -> term 0
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            dd_acc(acc.hi, acc.lo, vzw[u].y * ((vxy[u].x * vxy[u].x + vxy[u].y * vxy[u].y) + vzw[u].x * vzw[u].x));
-    }
-    acc = block_reduce_dd1<BLOCK>(acc);
-    if (threadIdx.x == 0)
-    {
-        part[blockIdx.x] = acc.hi;
-        part[gridDim.x + blockIdx.x] = acc.lo;
-    }
-}
-
-// one-launch variant: partials + fold by the last block + hand-off to the host
 template <int BLOCK, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
                                                               unsigned n, double* __restrict__ part,
@@ -524,22 +434,6 @@ __global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restr
     }
     acc = block_reduce_dd1<BLOCK>(acc);
     if (fold_by_last_block<BLOCK>(acc, part, ticket) && threadIdx.x == 0)
-    {
-        out[0] = 0.5 * (acc.hi + acc.lo);
-        publish_scalar(host, 0.5 * (acc.hi + acc.lo), sequence);
-    }
-}
-
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void kinetic_fold_kernel(const double* __restrict__ part, unsigned nparts,
-                                                             double* __restrict__ out, HostScalar* __restrict__ host,
-                                                             uint64_t sequence)
-{
-    DD acc {0.0, 0.0};
-    for (unsigned p = threadIdx.x; p < nparts; p += BLOCK)
-        dd_merge(acc.hi, acc.lo, part[p], part[nparts + p]);
-    acc = block_reduce_dd1<BLOCK>(acc);
-    if (threadIdx.x == 0)
     {
         out[0] = 0.5 * (acc.hi + acc.lo);
         publish_scalar(host, 0.5 * (acc.hi + acc.lo), sequence);

@@ -122,5 +122,5 @@ def test_no_product_kernel_uses_scratch_memory(capi):
     assert "scratch_" not in text
     names = " ".join(k for k, _ in kernels)
     for must in ("cavity_persistent_kernel", "dipole_partials_kernel", "force_map_aos_fused_kernel", "cavity_small_system_kernel",
-                 "kinetic_partials_kernel"):
+                 "kinetic_fused_kernel", "force_mass_fused_kernel"):
         assert must in names
