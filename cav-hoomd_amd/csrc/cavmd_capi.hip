@@ -188,7 +188,8 @@ int drain_profile(cavmd_workspace* ws)
 // Once a workspace has been captured its results are read behind a device synchronisation instead (include/cavmd.h).
 void note_capture(cavmd_workspace* ws, hipStream_t stream)
 {
-    if (ws->captured)
+    // (the null stream cannot be captured: HOOMD-blue's and torch's default path pays nothing for the query)
+    if (ws->captured || stream == nullptr)
         return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)

@@ -677,6 +677,8 @@ __global__ __launch_bounds__(BLOCK) void force_map_aos_fused_kernel(AosInput in,
     force_map_body<BLOCK, UNROLL, NT, true>(m, in.charge, in.pos2, N, prm.g, L_typeid, force2, c_first, reverse);
 }
 
+constexpr int kSmallSystemLdsCharges = 4096; // charges the single-block kernel keeps in LDS (32 KB); beyond: re-read
+
 // ---- small systems: ONE block, ONE launch ----------------------------------------------------------------------
 // The reference's production system is N = 501 (examples/init-0.gsd, 500 SLURM replicas of it).  At that size two
 // launches are pure latency (~4 us each); a single block that reduces, finalises and maps in one go halves it.  Used
@@ -690,6 +692,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
 {
     __shared__ double s_m[5];
     __shared__ int s_mi[2];
+    __shared__ double s_c[kSmallSystemLdsCharges]; // the charges, for the force phase (no second trip to global memory)
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
     Accum acc;
     constexpr int BATCH = 4; // particles in flight per lane
@@ -710,7 +713,11 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
             const double ry = AosInput::y(r[j]) + (double)r[j].iy * Ly;
             const double rz = AosInput::z(r[j]) + (double)r[j].iz * Lz;
             if (i < N)
+            {
                 acc.add(i, rx, ry, rz, r[j].c, AosInput::tag(r[j]), L_typeid);
+                if (i < (unsigned)kSmallSystemLdsCharges)
+                    s_c[i] = r[j].c;
+            }
         }
     }
     acc = block_reduce<BLOCK>(acc);
@@ -720,8 +727,6 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
         s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
         s_mi[0] = sc.photon;
         s_mi[1] = sc.nL;
-        write_result(res, sc, N, 1u, sequence);
-        publish_to_host(res_host, sc, N, 1u, sequence);
     }
     __syncthreads();
     const double Dqx = s_m[0], Dqy = s_m[1], Fx = s_m[2], Fy = s_m[3], Fz = s_m[4];
@@ -736,7 +741,8 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
         v2d v = zero;
         if (photon >= 0)
         {
-            const double sgc = ng * in.charge[p]; // ((-g) * charge) * Dq, src/CavityForceCompute.cc:194
+            const double c = p < (unsigned)kSmallSystemLdsCharges ? s_c[p] : in.charge[p];
+            const double sgc = ng * c; // ((-g) * charge) * Dq, src/CavityForceCompute.cc:194
             v = (v2d) {sgc * Dqx, sgc * Dqy};
             const bool typed_L = (nL > 1) && (__double2loint(in.pos2[2 * p + 1].y) == L_typeid);
             v = (odd || typed_L) ? zero : v;
@@ -744,6 +750,13 @@ __global__ __launch_bounds__(BLOCK) void cavity_small_system_kernel(AosInput in,
                 v = odd ? (v2d) {Fz, 0.0} : (v2d) {Fx, Fy};
         }
         force2[k] = v;
+    }
+    // The result goes to the host AFTER the force stores have been issued: its system-scope release (~0.6 us) then overlaps
+    // their drain instead of standing in front of them.
+    if (threadIdx.x == 0)
+    {
+        write_result(res, sc, N, 1u, sequence);
+        publish_to_host(res_host, sc, N, 1u, sequence);
     }
 }
 
