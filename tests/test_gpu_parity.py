@@ -581,6 +581,55 @@ def test_randomised_small_systems_one_workspace(ref, oracle_mod):
         check_parity(cfg, gpu, ref_eval(ref, oracle_mod, cfg))
 
 
+def test_randomised_mid_size_systems_one_workspace(ref, oracle_mod):
+    """60 seeded random systems of 2 049 ... 400 000 particles through ONE workspace and ONE set of device buffers: the
+    single-launch kernel's grid, tile depth, ragged tail and LDS footprint change from call to call while its granule slabs
+    and epoch word live on (a stale record of an earlier, larger grid must never be mistaken for a fresh one); photon
+    anywhere or absent, sometimes several L-typed particles, charge magnitudes from 1e-150 to 1e3."""
+    cap = 400_000
+    ws = _capi.Workspace(cap)
+    dev = "cuda"
+    pos_d = torch.empty((cap, 4), dtype=torch.float64, device=dev)
+    chg_d = torch.empty((cap,), dtype=torch.float64, device=dev)
+    img_d = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    frc_d = torch.empty((cap, 4), dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(4242)
+    for case in range(60):
+        n = int(rng.choice([rng.integers(2049, 9000), rng.integers(9000, 140_000), rng.integers(140_000, cap + 1)]))
+        L = tuple(float(v) for v in 10.0 ** rng.integers(0, 4) * rng.uniform(0.5, 2.0, 3))
+        photon_at = int(rng.integers(0, n)) if rng.random() < 0.9 else None
+        cfg = _random_cfg(n, seed=77_000 + case, photon_at=photon_at, L=L, image_range=int(rng.integers(0, 4)))
+        cfg["charge"] = cfg["charge"] * rng.choice([1.0, 1e-150, 1e-8, 1e3])
+        if photon_at is not None:
+            cfg["charge"][photon_at] = 0.0
+            if rng.random() < 0.15:                      # degenerate: more L-typed particles after the photon
+                extra = rng.integers(photon_at, n, 3)
+                cfg["typeid"][extra] = 2
+        cfg["params"] = {"omegac": float(10.0 ** rng.uniform(-3, 0)), "couplstr": float(10.0 ** rng.uniform(-4, 0)),
+                         "phmass": float(rng.uniform(0.5, 2.0))}
+        pos_d[:n].copy_(torch.from_numpy(oracle_mod.pack_pos(cfg["position"], cfg["typeid"])))
+        chg_d[:n].copy_(torch.from_numpy(cfg["charge"]))
+        img_d[:n].copy_(torch.from_numpy(cfg["image"]))
+        frc_d.fill_(float("nan"))
+        prm = _capi.make_params(cfg["params"]["omegac"], cfg["params"]["couplstr"], cfg["params"]["phmass"])
+        ws.compute_hoomd(0, n, pos_d.data_ptr(), chg_d.data_ptr(), img_d.data_ptr(), cfg["box"], 2, prm, frc_d.data_ptr())
+        torch.cuda.synchronize()
+        res = ws.result()
+        assert res.sequence == case + 1 and res.n_particles == n
+        assert np.isnan(frc_d[n:n + 64].cpu().numpy()).all(), "wrote past N"
+        refout = ref_eval(ref, oracle_mod, cfg)
+        gpu = {"force": frc_d[:n].cpu().numpy(), "energies": np.array(ws.energies()), "dipole": np.array(res.dipole[:]),
+               "photon_idx": res.photon_idx}
+        if res.n_photon_typed > 1:
+            # the L-sum detour costs one extra rounding: scale-relative bounds instead of the 2-ulp dipole test
+            assert gpu["photon_idx"] == refout["photon_idx"]
+            assert np.abs(gpu["dipole"] - refout["dipole"]).max() <= 1e-12 * np.abs(refout["dipole"]).max() + 1e-300
+            S = force_scales(cfg, refout)
+            assert np.all(np.abs(gpu["force"][:, :3] - refout["force"][:, :3]) <= 1e-10 * S[:, None] + 1e-300)
+        else:
+            check_parity(cfg, gpu, refout)
+
+
 # ---- observable that reuses the reduction (SURVEY.md 8f, row f2) ------------------------------------------------------------
 def test_total_dipole_observable(oracle_mod):
     """cavmd_result.total_dipole = the reference's compute_total_dipole_moment (src/cavitymd/analysis.py:18-31):
