@@ -3,8 +3,9 @@
 UNVERIFIED AGAINST A REAL HOOMD-blue: the build/test image has no HOOMD (``import hoomd`` raises
 ModuleNotFoundError), so this module is only ever imported when a user installs the package next to a
 HOOMD-blue 4.x ROCm build.  It is written against the HOOMD 4 Python API the reference itself uses
-(src/cavitymd/forces.py:45-173, src/cavitymd/cavity_force_python.py:31-149) and is exercised by no
-test here.  See INTEGRATION.md.
+(src/cavitymd/forces.py:45-173, src/cavitymd/cavity_force_python.py:31-149).  Its control flow is executed by
+tests/test_hoomd_plugin_stub.py against a STAND-IN hoomd package (tests/stubs/hoomd) -- that catches typos and checks
+this module's own logic, it says nothing about a real HOOMD-blue.  See INTEGRATION.md.
 
 Two attach routes, tried in this order (reference ladder: cuda -> cpp -> python, forces.py:97-173):
 

@@ -101,7 +101,9 @@ struct cavmd_workspace
     hipStream_t rho_stream = nullptr;
     bool rho_computed = false;
     double* d_mode = nullptr;
-    double* h_mode = nullptr; // pinned
+    HostMode* h_mode = nullptr;     // pinned, mapped, coherent: cavity_mode_kernel publishes here
+    HostMode* h_mode_dev = nullptr;
+    uint64_t mode_sequence = 0;
     double* d_fm_part = nullptr; // [2][max_parts] + 1 result
     HostScalar* h_fm = nullptr;     // pinned, mapped, coherent: the scalar reductions publish here, the host spins on `ready`
     HostScalar* h_fm_dev = nullptr; // device-side address of h_fm
@@ -906,15 +908,32 @@ int cavmd_cavity_mode(cavmd_workspace* ws, void* stream_, const cavmd_double4* d
     if (!ws->d_mode)
     {
         CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_mode, sizeof(double) * 4));
-        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_mode, sizeof(double) * 4, hipHostMallocDefault));
+        CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_mode, sizeof(HostMode), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(ws->h_mode, 0, sizeof(HostMode));
+        CAVMD_HIP_TRY(hipHostGetDevicePointer((void**)&ws->h_mode_dev, ws->h_mode, 0));
     }
     const cavmd_result* res = ws->d_result;
-    hipLaunchKernelGGL(cavity_mode_kernel, dim3(1), dim3(1), 0, stream, res, d_vel, kB, ws->d_mode);
+    ws->mode_sequence += 1;
+    hipLaunchKernelGGL(cavity_mode_kernel, dim3(1), dim3(1), 0, stream, res, d_vel, kB, ws->d_mode, ws->h_mode_dev,
+                       ws->mode_sequence);
     CAVMD_HIP_TRY(hipGetLastError());
-    CAVMD_HIP_TRY(hipMemcpyAsync(ws->h_mode, ws->d_mode, sizeof(double) * 4, hipMemcpyDeviceToHost, stream));
-    CAVMD_HIP_TRY(hipStreamSynchronize(stream));
+    // spin on the flag (the stream going idle ends the wait too, e.g. after a failed launch)
+    for (;;)
+    {
+        if (__atomic_load_n(&ws->h_mode->ready, __ATOMIC_ACQUIRE) == ws->mode_sequence)
+            break;
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess)
+        {
+            if (__atomic_load_n(&ws->h_mode->ready, __ATOMIC_ACQUIRE) != ws->mode_sequence)
+                return (int)hipErrorLaunchFailure;
+            break;
+        }
+        if (q != hipErrorNotReady)
+            return (int)q;
+    }
     for (int k = 0; k < 4; ++k)
-        out[k] = ws->h_mode[k];
+        out[k] = ws->h_mode->v[k];
     return CAVMD_OK;
 }
 

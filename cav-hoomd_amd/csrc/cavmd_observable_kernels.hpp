@@ -250,8 +250,15 @@ __global__ __launch_bounds__(BLOCK) void density_fold_kernel(const double* __res
 // Cavity-mode kinetic energy (reference: CavityModeTracker.compute_cavity_properties, src/cavitymd/analysis.py:1324-1368):
 // KE = 1/2 m v.v of the photon found by the last force evaluation; HOOMD keeps the mass in vel.w.
 // out[0..3] = KE, harmonic PE (from the result block), KE + PE, temperature = (2/3) KE / k_B.
+// The four numbers reach the host through mapped pinned memory: values first, then the call's sequence number
+// (system-scope release) that cavmd_cavity_mode spins on -- no copy, no stream synchronisation.
+struct HostMode
+{
+    double v[4];
+    uint64_t ready;
+};
 __global__ void cavity_mode_kernel(const cavmd_result* __restrict__ res, const cavmd_double4* __restrict__ vel, double kB,
-                                   double* __restrict__ out)
+                                   double* __restrict__ out, HostMode* __restrict__ host, uint64_t sequence)
 {
     const int p = res->photon_idx;
     double ke = 0.0, pe = 0.0, tot = 0.0, temp = 0.0;
@@ -267,6 +274,11 @@ __global__ void cavity_mode_kernel(const cavmd_result* __restrict__ res, const c
     out[1] = pe;
     out[2] = tot;
     out[3] = temp;
+    host->v[0] = ke;
+    host->v[1] = pe;
+    host->v[2] = tot;
+    host->v[3] = temp;
+    __hip_atomic_store(&host->ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 } // namespace cavmd
 

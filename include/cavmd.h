@@ -210,7 +210,7 @@ CAVMD_API int cavmd_density_field_read(cavmd_workspace* ws, double* h_out);
 /* Cavity-mode properties of CavityModeTracker (src/cavitymd/analysis.py:1324-1368) for the photon the last force
  * evaluation found: out = {KE = 1/2 m v.v, harmonic PE, KE + PE, T = (2/3) KE / k_B}; all zero without a photon.
  * d_vel is HOOMD's Scalar4 velocity array (mass in .w); kB in Hartree/K (the reference uses 3.167e-6).
- * Enqueues one tiny kernel and a 32-byte copy on `stream` and waits for them. */
+ * Enqueues one tiny kernel on `stream` and spins on its host-visible flag (no copy, no stream synchronisation). */
 CAVMD_API int cavmd_cavity_mode(cavmd_workspace* ws, void* stream, const cavmd_double4* d_vel, double kB, double out[4]);
 
 /* S = sum_i |F_i| / m_i over a Scalar4 net-force array and HOOMD's Scalar4 velocity array (mass in .w): the reduction
