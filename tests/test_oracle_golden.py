@@ -189,6 +189,42 @@ def test_forces_are_gradient_of_hamiltonian(ref, oracle_mod):
     assert np.all(F[:, 3] == 0.0)
 
 
+def test_forces_match_the_documented_equations_of_motion(ref, oracle_mod):
+    """A pin the reference itself holds: its theory chapter writes the equations of motion out (docs/theory.rst:16-24, one
+    mode; the single-mode restatement at :49-52 drops the parentheses around the two terms, the code and :16-19 keep them;
+    d_{n,lambda} = c_n r_{n,lambda}, so that the derivative of d w.r.t. R_n is the charge):
+        nuclei   F_n,lambda = -( eps q_lambda + eps^2 / (m w^2) * sum_l d_l,lambda ) * c_n          lambda = x, y
+        photon   m q''_lambda = -m w^2 q_lambda - eps * sum_n d_n,lambda
+    evaluated here literally, in exact rational arithmetic, and compared with the oracle's forces."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(17)
+    n = 40
+    L = (30.0, 20.0, 25.0)
+    pos = rng.uniform(-10, 10, (n, 3))
+    tid = (np.arange(n) % 2).astype(np.int32)
+    tid[-1] = 2
+    charge = rng.uniform(-1, 1, n)
+    charge[-1] = 0.0
+    image = rng.integers(-2, 3, (n, 3)).astype(np.int32)
+    omegac, eps, m = 0.31, 0.27, 1.7
+    p = ref.make_params(omegac, eps, m)
+    out = ref.compute(oracle_mod.pack_pos(pos, tid), charge, image, L, 2, p)
+    r = [[Fr(float(pos[i, k])) + int(image[i, k]) * Fr(float(L[k])) for k in range(3)] for i in range(n)]
+    q = r[-1]
+    d = [sum(Fr(float(charge[i])) * r[i][k] for i in range(n - 1)) for k in range(3)]
+    K = Fr(float(m)) * Fr(float(omegac)) ** 2                      # m w^2
+    e = Fr(float(eps))
+    for i in range(n - 1):
+        for k in range(2):
+            want = -(e * q[k] + e * e / K * d[k]) * Fr(float(charge[i]))
+            assert abs(float(want) - out["force"][i, k]) <= 1e-13 * max(abs(float(want)), 1e-30), (i, k)
+        assert out["force"][i, 2] == 0.0
+    for k in range(2):
+        want = -K * q[k] - e * d[k]
+        assert abs(float(want) - out["force"][-1, k]) <= 1e-13 * abs(float(want))
+    assert abs(float(-K * q[2]) - out["force"][-1, 2]) <= 1e-13 * abs(float(K * q[2]))   # z: free oscillator, no coupling
+
+
 def test_no_photon_and_empty(ref, oracle_mod):
     pos4 = oracle_mod.pack_pos(np.zeros((3, 3)), np.array([0, 1, 0]))
     out = ref.compute(pos4, np.ones(3), np.zeros((3, 3), dtype=np.int32), (1, 1, 1), 2, ref.make_params(1, 1, 1))
