@@ -211,6 +211,17 @@ int main(int argc, char** argv)
             CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
             unsigned long long t0 = ~0ull;
             for (unsigned b = 0; b < g1; ++b) t0 = std::min(t0, h[b * kStampSlots]);
+            if (rep == 29 && getenv("CAVMD_DUMP_BLOCKS"))
+            {
+                printf("  per block: b tiles start phase1_done tree_done\n");
+                const unsigned full_tiles = (unsigned)(N / (256 * unroll));
+                for (unsigned b = 0; b < g1; ++b)
+                {
+                    const unsigned nt = full_tiles > b ? (full_tiles - b + g1 - 1) / g1 : 0;
+                    printf("  blk %3u %u %.2f %.2f %.2f\n", b, nt, (double)(h[b * kStampSlots] - t0) * 0.01,
+                           (double)(h[b * kStampSlots + 1] - t0) * 0.01, (double)(h[b * kStampSlots + 2] - t0) * 0.01);
+                }
+            }
             if (rep == 29)
             {
                 printf("  per blockIdx%%8 group (start / tree done / fold done, us): ");
