@@ -124,3 +124,17 @@ def test_no_product_kernel_uses_scratch_memory(capi):
     for must in ("cavity_persistent_kernel", "dipole_partials_kernel", "force_map_aos_fused_kernel", "cavity_small_system_kernel",
                  "kinetic_fused_kernel", "force_mass_fused_kernel"):
         assert must in names
+
+
+def test_header_is_plain_c_and_links(capi, tmp_path):
+    """include/cavmd.h must be consumable by a C compiler (the boundary is a C ABI: no C++ types, no torch types): a C99
+    program (tests/c_abi/abi_check.c) is built with -pedantic -Werror against the header, linked with libcavmd.so and run."""
+    src = os.path.join(ROOT, "tests", "c_abi", "abi_check.c")
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                    "-L", libdir, "-lcavmd", "-lm", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "C-ABI-OK" in out.stdout, (out.returncode, out.stdout, out.stderr[-2000:])
+    if not torch.cuda.is_available():
+        assert "refused with CAVMD_ERR_NO_DEVICE" in out.stdout
