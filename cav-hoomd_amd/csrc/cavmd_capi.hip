@@ -76,6 +76,8 @@ struct cavmd_workspace
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
     int reduce_unroll = -1;       // particles per lane and tile of the reduction: -1 auto, 1 or 2
     int persistent = -1;          // -1 auto, 0 never, 1 whenever the grid is <= 256 blocks: ONE launch per evaluation
+    int persistent_lds_kb = 0;    // LDS budget per block of the single-launch kernel in KiB (0 = default: all of a CU's usable LDS
+                                  // when forced on, half of it when chosen automatically); tiles beyond it are read twice
     int persistent_balanced = -1; // partition of the particles over the blocks of the single-launch kernel: -1 auto, 0 tiles
                                   // dealt round-robin (the two-launch path's partition), 1 contiguous, equal shares
     // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
@@ -532,12 +534,15 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         }
         else
             slots = ((N + tile - 1) / tile + g1 - 1) / g1;
-        const size_t cap_slots = (kPersistMaxLds / (size_t)ws->reduce_blocks_per_cu - 1024) / (tile * sizeof(double));
+        size_t budget = kPersistMaxLds / (size_t)ws->reduce_blocks_per_cu - 1024;
+        if (ws->persistent_lds_kb > 0 && (size_t)ws->persistent_lds_kb * 1024 < budget)
+            budget = (size_t)ws->persistent_lds_kb * 1024;
+        const size_t cap_slots = budget / (tile * sizeof(double));
         const size_t lds_slots = slots < cap_slots ? slots : cap_slots;
         const size_t lds = lds_slots * tile * sizeof(double);
         const bool resident = g1 <= kMaxPersistGrid && ws->reduce_blocks_per_cu <= 4;
-        // auto: only while every tile of a block fits in LDS.  With overflow tiles the second phase (one block per CU, loads
-        // and stores of a tile back to back) is latency-bound: 170 us against 138 us for two launches at N = 1e7.
+        // auto: only while every tile of a block fits in LDS.  With overflow tiles re-read in the second phase (one block per
+        // CU) the kernel loses to two launches: 142 against 137 us at N = 1e7 (profiles/r02/ab_overflow.txt).
         // Nor by default beyond half a CU's LDS per block (N >~ 2.4e6): two such grids from different streams or processes
         // could then not be resident side by side, and two half-resident grids would wait for each other until their
         // bounded spins give up (a loud CAVMD_ERR_SYNC_TIMEOUT, but a failure).  persistent = 1 lifts both limits.
@@ -1211,6 +1216,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->reduce_unroll = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "persistent_lds_kb"))
+    {
+        if (value < 0 || value > 156)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->persistent_lds_kb = value;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "persistent_balanced"))
     {
         if (value < -1 || value > 1)
@@ -1243,6 +1255,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->persistent;
     else if (!strcmp(name, "reduce_unroll"))
         *value = ws->reduce_unroll;
+    else if (!strcmp(name, "persistent_lds_kb"))
+        *value = ws->persistent_lds_kb;
     else if (!strcmp(name, "persistent_balanced"))
         *value = ws->persistent_balanced;
     else

@@ -366,24 +366,8 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     const double ng = -prm.g;
     const size_t pchunk = 2 * (size_t)m.photon; // photon's first chunk
     const bool odd = tid & 1;                   // BLOCK is even, so the half is fixed per thread
-    for (unsigned slot = 0; slot < rg.nfull; ++slot)
-    {
-        const size_t p0 = rg.first + (size_t)slot * rg.step; // first particle of the tile
-        const size_t base = 2 * p0 + tid;
-        double c[MU];
-        if (slot < lds_slots)
-        {
-#pragma unroll
-            for (int u = 0; u < MU; ++u)
-                c[u] = s_charge[slot * TILE + ((u * BLOCK + tid) >> 1)];
-        }
-        else
-        {
-            // beyond the LDS budget (N >~ 5e6): these charges are read a second time, as the two-launch path reads all of them
-#pragma unroll
-            for (int u = 0; u < MU; ++u)
-                c[u] = __builtin_nontemporal_load(in.charge + p0 + ((u * BLOCK + tid) >> 1));
-        }
+    auto store_tile = [&](unsigned slot, const double (&c)[MU]) {
+        const size_t base = 2 * (rg.first + (size_t)slot * rg.step) + tid;
 #pragma unroll
         for (int u = 0; u < MU; ++u)
         {
@@ -394,6 +378,51 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             if ((k | 1) == (pchunk | 1))
                 v = odd ? (v2d) {m.Fz, 0.0} : (v2d) {m.Fx, m.Fy};
             store_chunk<NT_STORE>(force2 + k, v);
+        }
+    };
+    const unsigned resident = rg.nfull < lds_slots ? rg.nfull : lds_slots;
+    for (unsigned slot = 0; slot < resident; ++slot)
+    {
+        double c[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u)
+            c[u] = s_charge[slot * TILE + ((u * BLOCK + tid) >> 1)];
+        store_tile(slot, c);
+    }
+    if (resident < rg.nfull)
+    {
+        // Tiles beyond the LDS budget: their charges are read a second time (as the two-launch path reads all of them), D
+        // tiles per batch and two batches in flight (ping-pong register sets): the loads of the next batch are issued before
+        // the stores of the current one, so the wave only ever waits for loads that have had a batch of stores to land.
+        constexpr int D = 8;
+        auto load_batch = [&](unsigned s0, double (&c)[D][MU]) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+            {
+                const unsigned slot = s0 + d < rg.nfull ? s0 + d : rg.nfull - 1; // clamped: no branch around the loads
+                const size_t p0 = rg.first + (size_t)slot * rg.step;
+#pragma unroll
+                for (int u = 0; u < MU; ++u)
+                    c[d][u] = __builtin_nontemporal_load(in.charge + p0 + ((u * BLOCK + tid) >> 1));
+            }
+        };
+        auto store_batch = [&](unsigned s0, const double (&c)[D][MU]) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (s0 + d < rg.nfull)
+                    store_tile(s0 + d, c[d]);
+        };
+        double A[D][MU], B[D][MU];
+        load_batch(resident, A);
+        for (unsigned s0 = resident; s0 < rg.nfull; s0 += 2 * D)
+        {
+            if (s0 + D < rg.nfull)
+                load_batch(s0 + D, B);
+            store_batch(s0, A);
+            if (s0 + 2 * D < rg.nfull)
+                load_batch(s0 + 2 * D, A);
+            if (s0 + D < rg.nfull)
+                store_batch(s0 + D, B);
         }
     }
     if (rg.tail_count)

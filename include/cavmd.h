@@ -289,6 +289,8 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  The kernel's workgroups wait for each other inside the launch: they must all be
  *                                  resident together; every wait is bounded and a give-up is reported as
  *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces.
+ *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles
+ *                                  beyond it are read a second time
  *   "persistent_balanced"  -1..1   partition of the particles over the blocks of the single-launch kernel: 0 tiles dealt
  *                                  round-robin (the two-launch path's partition: then also its bits), 1 contiguous equal
  *                                  shares, -1 auto
