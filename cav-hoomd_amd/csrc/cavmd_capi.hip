@@ -76,6 +76,9 @@ struct cavmd_workspace
     int small_system_max_n = kSmallSystemMaxN; // at or below this N: one single-block launch does everything; 0 disables
     int reduce_unroll = -1;       // particles per lane and tile of the reduction: -1 auto, 1 or 2
     int persistent = -1;          // -1 auto, 0 never, 1 whenever the grid is <= 256 blocks: ONE launch per evaluation
+    int rho_lane_particle = -1;   // density field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
+                                  // wavevectors per chunk, -1 auto (lane = particle with 5 where n_k fills the 64-lane
+                                  // chunks of the first mapping to less than 3/4)
     int persistent_lds_kb = 0;    // LDS budget per block of the single-launch kernel in KiB (0 = default: all of a CU's usable LDS
                                   // when forced on, half of it when chosen automatically); tiles beyond it are read twice
     int persistent_balanced = -1; // partition of the particles over the blocks of the single-launch kernel: -1 auto, 0 tiles
@@ -851,7 +854,8 @@ int cavmd_set_wavevectors(cavmd_workspace* ws, size_t n_k, const double* h_wavev
     ws->rho_computed = false;
     ws->n_k = n_k;
     ws->n_chunks = (unsigned)((n_k + kWave - 1) / kWave);
-    ws->rho_blocks = (unsigned)ws->num_cu; // one 1024-thread block (16 waves, 4 per SIMD) per CU: few partials to fold
+    ws->rho_blocks = (unsigned)ws->num_cu * 4; // capacity of the partial buffer: three 256-thread blocks per CU (lane = particle
+                                               // mapping) or one 1024-thread block per CU (lane = wavevector)
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_kvec, sizeof(double) * 3 * n_k));
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho_part, sizeof(double) * 2 * kWave * (size_t)ws->n_chunks * ws->rho_blocks));
     CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_rho, sizeof(double) * 2 * n_k));
@@ -872,17 +876,45 @@ int cavmd_density_field(cavmd_workspace* ws, void* stream_, size_t N, const doub
     DeviceGuard guard(ws->device);
     constexpr int kBlock = 1024;
     const size_t tiles = (N + kWave - 1) / kWave;
-    size_t gb = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
-    if (gb > ws->rho_blocks)
-        gb = ws->rho_blocks;
-    if (gb == 0)
-        gb = 1;
-    hipLaunchKernelGGL((density_partials_kernel<kBlock>), dim3((unsigned)gb, ws->n_chunks), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const char*>(d_position), position_stride, (unsigned)N, ws->d_kvec,
-                       (unsigned)ws->n_k, make_sincos_coef(), ws->d_rho_part);
+    unsigned gb;
+    // lane = wavevector costs ceil(n_k / 64) * 64 lane-slots per particle, lane = particle n_k slots that measured 1.33x
+    // as expensive each (N = 1e6: n_k = 17: 53 vs 87 us, 50: 99 vs 95, 64: 118 vs 88, 100: 170 vs 165)
+    int lp = ws->rho_lane_particle;
+    if (lp < 0)
+        lp = (ws->n_k * 4 < (size_t)ws->n_chunks * kWave * 3) ? 3 : 0;
+    if (lp)
+    {
+        // lane = particle: 256-thread blocks, KC wavevectors per chunk (2 KC running sums per lane in registers)
+        constexpr int kLpBlock = 256;
+        size_t g = (tiles + (kLpBlock / kWave) - 1) / (kLpBlock / kWave);
+        if (g > ws->rho_blocks)
+            g = ws->rho_blocks;
+        gb = (unsigned)(g ? g : 1);
+#define CAVMD_LAUNCH_LP(KCV)                                                                                              \
+    hipLaunchKernelGGL((density_partials_lp_kernel<kLpBlock, KCV>), dim3(gb, (unsigned)((ws->n_k + KCV - 1) / KCV)),        \
+                       dim3(kLpBlock), 0, stream, reinterpret_cast<const char*>(d_position), position_stride, (unsigned)N, \
+                       ws->d_kvec, (unsigned)ws->n_k, make_sincos_coef(), ws->d_rho_part);
+        if (lp == 1)
+            CAVMD_LAUNCH_LP(25)
+        else if (lp == 2)
+            CAVMD_LAUNCH_LP(10)
+        else
+            CAVMD_LAUNCH_LP(5)
+#undef CAVMD_LAUNCH_LP
+    }
+    else
+    {
+        size_t g = (tiles + (kBlock / kWave) - 1) / (kBlock / kWave);
+        if (g > (size_t)ws->num_cu)
+            g = (size_t)ws->num_cu;
+        gb = (unsigned)(g ? g : 1);
+        hipLaunchKernelGGL((density_partials_kernel<kBlock>), dim3(gb, ws->n_chunks), dim3(kBlock), 0, stream,
+                           reinterpret_cast<const char*>(d_position), position_stride, (unsigned)N, ws->d_kvec,
+                           (unsigned)ws->n_k, make_sincos_coef(), ws->d_rho_part);
+    }
     CAVMD_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL((density_fold_kernel<kBlock>), dim3(ws->n_chunks), dim3(kBlock), 0, stream, ws->d_rho_part,
-                       (unsigned)gb, (unsigned)ws->n_k, ws->d_rho);
+                       gb, (unsigned)ws->n_k, ws->d_rho);
     CAVMD_HIP_TRY(hipGetLastError());
     ws->rho_stream = stream;
     ws->rho_computed = true;
@@ -1216,6 +1248,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->reduce_unroll = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "rho_lane_particle"))
+    {
+        if (value < -1 || value > 3)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->rho_lane_particle = value;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "persistent_lds_kb"))
     {
         if (value < 0 || value > 156)
@@ -1255,6 +1294,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->persistent;
     else if (!strcmp(name, "reduce_unroll"))
         *value = ws->reduce_unroll;
+    else if (!strcmp(name, "rho_lane_particle"))
+        *value = ws->rho_lane_particle;
     else if (!strcmp(name, "persistent_lds_kb"))
         *value = ws->persistent_lds_kb;
     else if (!strcmp(name, "persistent_balanced"))

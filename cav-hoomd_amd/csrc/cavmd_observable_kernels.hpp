@@ -196,6 +196,132 @@ __global__ __launch_bounds__(BLOCK) void density_partials_kernel(const char* __r
     }
 }
 
+// ---- second mapping: LANE = PARTICLE ------------------------------------------------------------------------------------
+// With lane = wavevector a wave runs at n_k / 64 of its rate when n_k is not a multiple of 64 (the reference's default of
+// 50 wavevectors leaves 14 lanes idle: 22 % of a kernel that is bound by fp64 instruction issue).  Here a lane owns one
+// particle of a 64-particle tile and walks a chunk of KC wavevectors, which arrive through the scalar path (uniform
+// addresses -> s_load, SGPR operands); each lane keeps 2 KC running sums in registers (KC = 25: 100 VGPRs), all 64 lanes
+// are busy, and the KC independent sincos chains of a tile interleave by themselves.  The sums over lanes, waves and blocks
+// come afterwards: wave tree, LDS, then density_fold_kernel on the same [chunk-of-64][block][2][64] partial layout as the
+// first mapping.  Same term arithmetic (k.r association, sincos) as density_partials_kernel.
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<0xB1, 0xF>(v, 0.0);
+    v += dpp_f64<0x4E, 0xF>(v, 0.0);
+    v += dpp_f64<0x124, 0xF>(v, 0.0);
+    v += dpp_f64<0x128, 0xF>(v, 0.0);
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+template <int BLOCK, int KC>
+__global__ __launch_bounds__(BLOCK) void density_partials_lp_kernel(const char* __restrict__ pos, size_t pos_stride, unsigned N,
+                                                                    const double* __restrict__ kvec, unsigned n_k,
+                                                                    SinCosCoef coef, double* __restrict__ part)
+{
+    constexpr int NW = BLOCK / kWave;
+    __shared__ double s_acc[NW][2 * KC];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const unsigned k0 = blockIdx.y * KC;
+    const unsigned kcount = n_k - k0 < (unsigned)KC ? n_k - k0 : (unsigned)KC; // wave-uniform
+    // the largest |kx| + |ky| + |kz| of the chunk, for the one range check per tile
+    double ksum = 0.0;
+    for (unsigned kk = 0; kk < kcount; ++kk)
+    {
+        const double* kv = kvec + 3 * (size_t)(k0 + kk);
+        ksum = fmax(ksum, (fabs(kv[0]) + fabs(kv[1])) + fabs(kv[2]));
+    }
+    // the chunk's wavevectors, loaded once: uniform values, so they live in SGPRs (a padded kk of the last, partial chunk
+    // repeats the chunk's first wavevector; it is never stored)
+    double kx[KC], ky[KC], kz[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+    {
+        const double* kv = kvec + 3 * (size_t)(k0 + ((unsigned)kk < kcount ? kk : 0));
+        kx[kk] = kv[0];
+        ky[kk] = kv[1];
+        kz[kk] = kv[2];
+    }
+    double re[KC], im[KC];
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+        re[kk] = im[kk] = 0.0;
+    const unsigned ntiles = (N + kWave - 1) / kWave;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    const unsigned gw = blockIdx.x * NW + wave_u, GW = gridDim.x * NW;
+    // the position of the NEXT tile is fetched while the current one is being worked on (a tile is only KC sincos per lane:
+    // without the prefetch every tile starts with an exposed global-load latency)
+    auto fetch = [&](unsigned tile, double& x, double& y, double& z) {
+        size_t i = (size_t)tile * kWave + lane;
+        i = i < N ? i : (size_t)N - 1;
+        const double* p = reinterpret_cast<const double*>(pos + i * pos_stride);
+        x = p[0];
+        y = p[1];
+        z = p[2];
+    };
+    double nx = 0.0, ny = 0.0, nz = 0.0;
+    if (gw < ntiles)
+        fetch(gw, nx, ny, nz);
+    for (unsigned tile = gw; tile < ntiles; tile += GW)
+    {
+        const bool valid = (size_t)tile * kWave + lane < N; // false only in the lanes beyond N of the last tile
+        const double px = nx, py = ny, pz = nz;
+        if (tile + GW < ntiles)
+            fetch(tile + GW, nx, ny, nz);
+        const double m = fmax(fmax(fabs(px), fabs(py)), fabs(pz));
+        // fast path (wave-uniform): every |k . r| of this tile and chunk is below 1e8 (and finite), no padding lanes
+        if (!__any(!(ksum * m < 1.0e8) || !valid))
+        {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+            {
+                double sn, cs;
+                sincos_reduced(coef, (px * kx[kk] + py * ky[kk]) + pz * kz[kk], sn, cs);
+                re[kk] += cs;
+                im[kk] += sn;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+            {
+                const double kr = (px * kx[kk] + py * ky[kk]) + pz * kz[kk];
+                double sn, cs;
+                if (__any(!(fabs(kr) < 1.0e8))) // wave-uniform; also catches NaN/Inf
+                    sincos(kr, &sn, &cs);
+                else
+                    sincos_reduced(coef, kr, sn, cs);
+                re[kk] += valid ? cs : 0.0;
+                im[kk] += valid ? sn : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+    {
+        const double r = wave_sum_f64(re[kk]), q = wave_sum_f64(im[kk]);
+        if (lane == 0)
+        {
+            s_acc[wave][2 * kk] = r;
+            s_acc[wave][2 * kk + 1] = q;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kcount)
+    {
+        double v = s_acc[0][threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv)
+            v += s_acc[wv][threadIdx.x];
+        const unsigned k = k0 + threadIdx.x / 2, c = threadIdx.x & 1;
+        // the [chunk-of-64][block][2][64] layout density_fold_kernel reads
+        part[(((size_t)(k / kWave) * gridDim.x + blockIdx.x) * 2 + c) * kWave + (k % kWave)] = v;
+    }
+}
+
 // one block per chunk of 64 wavevectors: thread (w, lane) folds blocks w, w+NW, ... of wavevector `lane` with TwoSum,
 // the NW waves meet in LDS.  out: interleaved (re, im) per wavevector.
 template <int BLOCK>

@@ -289,6 +289,8 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  The kernel's workgroups wait for each other inside the launch: they must all be
  *                                  resident together; every wait is bounded and a give-up is reported as
  *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces.
+ *   "rho_lane_particle"    -1..3   density-field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
+ *                                  wavevectors per chunk, -1 auto by n_k
  *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles
  *                                  beyond it are read a second time
  *   "persistent_balanced"  -1..1   partition of the particles over the blocks of the single-launch kernel: 0 tiles dealt

@@ -27,17 +27,20 @@ def test_density_field_matches_reference_expression(n_mol, n_k, kmag):
     k = (obs.fibonacci_sphere(n_k) if n_k > 1 else np.array([[0.3, -0.4, 1.2]])) * kmag
     pd = _pdata(cfg)
     field = prod.DensityField(pd, k)
-    got = field.compute()
     n = pd.getN()
     want = obs.density_field(cfg["position"], k)            # the reference's expression (numpy)
     exact = obs.density_field_exact(cfg["position"], k)     # same phases, exactly rounded sums
-    assert got.shape == (n_k,)
-    assert np.abs(got - want).max() <= 1e-12 * n
-    assert np.abs(got - exact).max() <= 1e-13 * n
-    # repeatable bit for bit, and usable on a side stream
-    side = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    assert np.array_equal(field.compute(stream=side), got)
+    # every mapping of the kernel: chosen automatically, lane = wavevector, lane = particle with 25 / 10 / 5 per chunk
+    for mapping in (-1, 0, 1, 2, 3):
+        field._ws.set_tunable("rho_lane_particle", mapping)
+        got = field.compute()
+        assert got.shape == (n_k,)
+        assert np.abs(got - want).max() <= 1e-12 * n, mapping
+        assert np.abs(got - exact).max() <= 1e-13 * n, mapping
+        # repeatable bit for bit, and usable on a side stream
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        assert np.array_equal(field.compute(stream=side), got)
 
 
 def test_sincos_term_accuracy_through_single_particle():
