@@ -8,7 +8,7 @@ Same constructor and method names as ``_cavitymd.CavityForceCompute[GPU]``
     .getHarmonicEnergy() / .getCouplingEnergy() / .getDipoleSelfEnergy()
     .compute(timestep)            # HOOMD: ForceCompute::compute -> computeForces(timestep)
 
-The work itself is two HIP kernel launches (one for systems of up to 2048 particles) behind the C ABI
+The work itself is one HIP kernel launch (two above ~2.4e6 particles) behind the C ABI
 (``include/cavmd.h``); this class only owns the force array (HOOMD: ``m_force``), the workspace and the parameter
 block.  There is no CPU fallback.  The call goes through the pybind11 module when it is built (less host overhead
 per call), else through ctypes; ``CAVMD_BINDING=ctypes`` forces the latter.

@@ -315,8 +315,9 @@ def test_ragged_sizes_and_photon_positions(ref, oracle_mod, n):
         refout = ref_eval(ref, oracle_mod, cfg)
         check_parity(cfg, gpu_eval(cfg), refout)
         if n <= 4097:
-            # both code paths at small N: the single-block launch (default up to 2048) and the two-launch path
+            # every code path at small N: the single-block launch (default up to 1200), several blocks (one launch or two)
             check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 0}), refout)
+            check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 0, "persistent": 0}), refout)
             check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 8192}), refout)
 
 
