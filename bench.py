@@ -205,12 +205,12 @@ def percentiles(samples_ms):
 
 
 def roofline_block(n, kt_ms):
-    """kt_ms = mean device time of {slot 0, slot 1, slot 2}.  Single-launch evaluation (the default for 1200 < N <~ 2.4e6):
+    """kt_ms = mean device time of {slot 0, slot 1, slot 2}.  Single-launch evaluation (the default for 1024 < N <~ 2.4e6):
     slot 0 holds the one kernel and its algorithmic bytes are the evaluation's 92 N (a fused kernel that
     keeps the charges on-chip moves 84 N, the figure is still priced at 92 N).  Two launches: slot 0 = reduction (52 N),
     slot 2 = fused force map (40 N); three launches add the finalize kernel in slot 1 (no algorithmic bytes)."""
     if kt_ms[2] <= 0 and kt_ms[1] <= 0:
-        names = ("cavity_persistent_kernel" if n > 1200 else "cavity_small_system_kernel", "", "")
+        names = ("cavity_persistent_kernel" if n > 1024 else "cavity_small_system_kernel", "", "")
         bytes_per_launch = (BYTES_EVAL * n, 0, 0)
     else:
         names = ("dipole_partials_kernel", "finalize_kernel", "force_map_aos_fused_kernel")

@@ -34,8 +34,9 @@ constexpr int kEventsPerSlot = 6;
 constexpr int kProfileSlots = 512; // evaluations buffered between profile reads
 constexpr size_t kMaxSamples = 4096;
 constexpr int kSmallBlock = 256;
-constexpr int kSmallSystemMaxN = 1200;         // single-block path wins below ~1200 particles against the single-launch kernel (5.3 vs 7.3 us
-                                               // at N = 501, 7.1 vs 7.5 at 1101, 8.0 vs 7.4 at 1401, 9.2 vs 7.6 at 2001: profiles/r02/ab_small_system.txt)
+constexpr int kSmallSystemMaxN = 1024;         // single-block path (one batch of 4 x 256 particles) wins up to ~1000 particles against the
+                                               // single-launch kernel: 5.0 vs 6.0 us at N = 501, 6.0 vs 6.0 at 1001, 7.0 vs 6.1 at 1101,
+                                               // 7.9 vs 6.2 at 1401 (profiles/r02/ab_small_system.txt)
 constexpr size_t kNtStoreMinN = 200000;       // force stores: neutral at 1e5, -3.6 % at 3e5, -4.3 % at 1e6, -5.8 % at 1e7
 constexpr size_t kChargeTemporalMaxN = 25000000; // charges stay temporal while the 8 N bytes fit in the 256 MiB Infinity Cache
                                                  // next to the streams: re-measured in round 2 (the round-1 crossover at

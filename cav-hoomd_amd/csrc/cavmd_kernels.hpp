@@ -1,7 +1,7 @@
 // cavmd_kernels.hpp -- CDNA4 (gfx950) device code of the cavity-force path (umbrella header).
 //
-// An evaluation is ONE launch for 1200 < N <~ 2.4e6 (cavmd_persistent_kernel.hpp: both phases below in one grid of
-// co-resident blocks, charges kept in LDS between them), one single-block launch up to 1200 particles, and otherwise
+// An evaluation is ONE launch for 1024 < N <~ 2.4e6 (cavmd_persistent_kernel.hpp: both phases below in one grid of
+// co-resident blocks, charges kept in LDS between them), one single-block launch up to 1024 particles, and otherwise
 // TWO launches, all bandwidth- or latency-bound (no MFMA: ~60 VALU operations per 92 bytes):
 //
 //   dipole_partials_kernel       streams pos (32 B) + charge (8 B) + image (12 B) per particle, unwraps, forms the addends

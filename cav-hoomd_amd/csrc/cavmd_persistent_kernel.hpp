@@ -266,29 +266,39 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         if (b != CAVMD_FAULT_SILENT_BLOCK)
 #endif
         publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc, s_words);
-        if ((b & (kGroup - 1)) == 0)
-        {
-            // Level 1: the first block of group b / 16 gathers the group's records (its own from registers), folds them and
-            // publishes the group total.  (Letting EVERY block take one look at its group on arrival, so that the last
-            // arriver folds without waiting to be seen, measured slower: 9.30 vs 9.15 us at N = 1e5, 19.9 vs 19.75 at 1e6 --
-            // 240 extra gathers in flight when the last records land.)
-            const unsigned count = min(G - b, (unsigned)kGroup);
-            Accum o, t;
-            ok = gather_records(block_slab, b, count, tag, s_words, o, kSpinLimit, 0, acc);
-            // (a group whose gather timed out publishes nothing: every block then times out on the group totals and the
-            // whole evaluation fails loudly, instead of a wrong total spreading with a valid tag)
-            if (ok)
-            {
-                t.merge(o);
-                t = row_fold16(t);
-                publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t, s_words);
-            }
-        }
-        CAVMD_PSTAMP(7);
         Accum o, t;
-        ok = gather_records(group_slab + (size_t)(b % kGroupCopies) * kGroup * kGranulesPerRecord, 0, (G + kGroup - 1) / kGroup,
-                            tag, s_words, o, kSpinLimit, -1, acc)
-             && ok;
+        if (G <= (unsigned)kGroup)
+        {
+            // A grid of at most 16 blocks (N up to ~4000) is ONE group: every block gathers the block records itself, its own
+            // from registers -- one hop instead of two, and the same fold (the second level would only add zeros).
+            ok = gather_records(block_slab, 0, G, tag, s_words, o, kSpinLimit, (int)b, acc);
+            CAVMD_PSTAMP(7);
+        }
+        else
+        {
+            if ((b & (kGroup - 1)) == 0)
+            {
+                // Level 1: the first block of group b / 16 gathers the group's records (its own from registers), folds them
+                // and publishes the group total.  (Letting EVERY block take one look at its group on arrival, so that the
+                // last arriver folds without waiting to be seen, measured slower: 9.30 vs 9.15 us at N = 1e5, 19.9 vs 19.75 at
+                // 1e6 -- 240 extra gathers in flight when the last records land.)
+                const unsigned count = min(G - b, (unsigned)kGroup);
+                Accum o1, t1;
+                ok = gather_records(block_slab, b, count, tag, s_words, o1, kSpinLimit, 0, acc);
+                // (a group whose gather timed out publishes nothing: every block then times out on the group totals and
+                // the whole evaluation fails loudly, instead of a wrong total spreading with a valid tag)
+                if (ok)
+                {
+                    t1.merge(o1);
+                    t1 = row_fold16(t1);
+                    publish_record(group_slab, kGroup, kGroupCopies, b / kGroup, tag, t1, s_words);
+                }
+            }
+            CAVMD_PSTAMP(7);
+            ok = gather_records(group_slab + (size_t)(b % kGroupCopies) * kGroup * kGranulesPerRecord, 0,
+                                (G + kGroup - 1) / kGroup, tag, s_words, o, kSpinLimit, -1, acc)
+                 && ok;
+        }
         t.merge(o);
         const Accum tot = row_fold16(t);
         CAVMD_PSTAMP(3);

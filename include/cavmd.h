@@ -280,7 +280,7 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "reduce_nt_load"       -1..2   -1 auto by N, 0 plain, 1 pos+image non-temporal, 2 all non-temporal
  *   "fused_finalize"       0/1     1: two launches per evaluation (finalize folded into the force map), 0: three
  *   "map_reverse"          -1..1   -1 auto by N, 1: the force map walks its tiles last-to-first, 0: first-to-last
- *   "small_system_max_n"   0..2^20 at or below this N (default 1200) one single-block launch does the whole evaluation (0 = never)
+ *   "small_system_max_n"   0..2^20 at or below this N (default 1024) one single-block launch does the whole evaluation (0 = never)
  *   "reduce_unroll"        -1,1,2  particles per lane and tile of the reduction (-1 auto by N)
  *   "persistent"           -1..1   ONE launch per evaluation (reduction, in-launch all-reduce of the partials, force map from
  *                                  charges kept in LDS): 1 whenever the grid is <= 256 blocks, 0 never (two launches),

@@ -315,7 +315,7 @@ def test_ragged_sizes_and_photon_positions(ref, oracle_mod, n):
         refout = ref_eval(ref, oracle_mod, cfg)
         check_parity(cfg, gpu_eval(cfg), refout)
         if n <= 4097:
-            # every code path at small N: the single-block launch (default up to 1200), several blocks (one launch or two)
+            # every code path at small N: the single-block launch (default up to 1024), several blocks (one launch or two)
             check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 0}), refout)
             check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 0, "persistent": 0}), refout)
             check_parity(cfg, gpu_eval(cfg, {"small_system_max_n": 8192}), refout)
