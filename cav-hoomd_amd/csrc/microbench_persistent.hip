@@ -113,6 +113,8 @@ int main(int argc, char** argv)
     const bool nts = N >= 200000;
 #define ALLOW(UNR, NTS) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
     ALLOW(1, false); ALLOW(1, true); ALLOW(2, false); ALLOW(2, true);
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 
 #ifdef CAVMD_FAULT_SILENT_BLOCK
     {
@@ -169,6 +171,20 @@ int main(int argc, char** argv)
     };
     V.push_back({"single launch, tiles dealt round-robin", [&](int f) { persist(f, 1, false); }, {}});
     V.push_back({"single launch, balanced contiguous shares", [&](int f) { persist(f, 1, true); }, {}});
+    auto persist512 = [&](int f, int unr) {
+        const size_t tile = 512 * unr;
+        const unsigned g1 = grid(N, tile, 1);
+        size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        const size_t cap = (156 * 1024 - 1024) / (tile * 8);
+        const unsigned lds_slots = (unsigned)std::min(slots, cap);
+        const size_t lds = (size_t)lds_slots * tile * 8;
+        if (unr == 1) hipLaunchKernelGGL((cavity_persistent_kernel<512, 1, true>), dim3(g1), dim3(512), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f], lds_slots, false);
+        else hipLaunchKernelGGL((cavity_persistent_kernel<512, 2, true>), dim3(g1), dim3(512), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f], lds_slots, false);
+    };
+    if (getenv("CAVMD_TRY_512")) {
+        V.push_back({"single launch, 512 threads x 1", [&](int f) { persist512(f, 1); }, {}});
+        V.push_back({"single launch, 512 threads x 2", [&](int f) { persist512(f, 2); }, {}});
+    }
 
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
