@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -88,6 +89,7 @@ struct cavmd_workspace
     // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
     unsigned long long* d_granules = nullptr;
     unsigned* d_epoch = nullptr;
+    bool sync_timeout_seen = false; // an inter-workgroup wait of the single-launch kernel gave up once: two launches from then on
     bool captured = false; // some evaluation was enqueued into a stream capture: the host-side flag protocol is off
     // profiling
     bool profiling = false;
@@ -373,6 +375,14 @@ int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
         return (int)hipErrorOutOfMemory;
     ws->device = device;
     ws->max_N = max_N;
+    // deployment-level switch for GPUs shared by several processes (see "persistent" in cavmd.h): CAVMD_PERSISTENT=0|1
+    if (const char* env = getenv("CAVMD_PERSISTENT"))
+    {
+        if (!strcmp(env, "0"))
+            ws->persistent = 0;
+        else if (!strcmp(env, "1"))
+            ws->persistent = 1;
+    }
     DeviceGuard guard(device);
 
     hipDeviceProp_t prop;
@@ -461,6 +471,24 @@ int cavmd_destroy(cavmd_workspace* ws)
     return CAVMD_OK;
 }
 
+namespace
+{
+// A single-launch evaluation whose blocks were not resident together ends in a time-out (NaN forces, sync_error raised in
+// the host-visible block).  Whoever notices first -- the next enqueue or the result read -- turns the single-launch path
+// off for this workspace for good: the condition that starved the grid (other grids holding the CUs' LDS) is a property
+// of the deployment, not of one step, and the two-launch path does not depend on residency.
+bool consume_sync_timeout(cavmd_workspace* ws)
+{
+    if (!ws->h_result || !__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
+        return false;
+    __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
+    ws->sync_timeout_seen = true;
+    ws->persistent = 0;
+    ws->computed = false; // the result block still holds the evaluation BEFORE the failed one
+    return true;
+}
+} // namespace
+
 int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavmd_double4* d_pos, const double* d_charge,
                         const cavmd_int3* d_image, double Lx, double Ly, double Lz, int L_typeid,
                         const cavmd_params* params, cavmd_double4* d_force)
@@ -476,6 +504,10 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         return CAVMD_ERR_CAPACITY;
     if (!params_ok(params))
         return CAVMD_ERR_BAD_PARAMS;
+    // an EARLIER evaluation timed out (its forces are NaN) and nobody read the result since: report it here, nothing is
+    // enqueued by this call; the next call takes the two-launch path
+    if (consume_sync_timeout(ws))
+        return CAVMD_ERR_SYNC_TIMEOUT;
 
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
@@ -799,14 +831,10 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
                 return (int)q;
         }
     }
-    if (__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
-    {
-        // The evaluation failed loudly (NaN forces).  The result block still holds the PREVIOUS evaluation: invalidate it, so
-        // that a second read reports "nothing computed" instead of handing that out as if it were current.
-        __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
-        ws->computed = false;
+    // The evaluation failed loudly (NaN forces).  The result block still holds the PREVIOUS evaluation: it is invalidated,
+    // so that a second read reports "nothing computed" instead of handing that out as if it were current.
+    if (consume_sync_timeout(ws))
         return CAVMD_ERR_SYNC_TIMEOUT;
-    }
     memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
     return CAVMD_OK;
 }
@@ -1243,6 +1271,18 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->persistent = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "sync_timeout_seen"))
+    {
+        // fault-injection hook (value 1): raises the time-out flag of the host-visible block exactly as a starved single-launch
+        // kernel would, so that callers and tests can exercise their handling; 0 forgets a time-out seen earlier
+        if (value < 0 || value > 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        if (value)
+            __atomic_store_n(&ws->h_result->sync_error, 1u, __ATOMIC_RELEASE);
+        else
+            ws->sync_timeout_seen = false;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "reduce_unroll"))
     {
         if (value != -1 && value != 1 && value != 2)
@@ -1294,6 +1334,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->small_system_max_n;
     else if (!strcmp(name, "persistent"))
         *value = ws->persistent;
+    else if (!strcmp(name, "sync_timeout_seen"))
+        *value = ws->sync_timeout_seen ? 1 : 0;
     else if (!strcmp(name, "reduce_unroll"))
         *value = ws->reduce_unroll;
     else if (!strcmp(name, "rho_lane_particle"))

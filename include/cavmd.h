@@ -288,7 +288,15 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  concurrent grids (other streams, other processes on the same GPU) can both be resident.
  *                                  The kernel's workgroups wait for each other inside the launch: they must all be
  *                                  resident together; every wait is bounded and a give-up is reported as
- *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces.
+ *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces -- by the result read or by the NEXT cavmd_compute_*
+ *                                  call, whichever comes first (that call enqueues nothing) -- and the workspace then
+ *                                  stays on two launches ("persistent" reads 0, "sync_timeout_seen" reads 1): a grid that
+ *                                  was starved once will be again while the GPU is shared the same way.  GPUs shared by
+ *                                  more processes than fit (LDS per block x processes > 160 KB; five at N = 1e6, two at
+ *                                  2.4e6) should set the environment variable CAVMD_PERSISTENT=0, read by cavmd_create
+ *                                  (=1 forces the single launch).
+ *   "sync_timeout_seen"    0/1     read: 1 after such a time-out.  Write 1: fault-injection hook, raises the time-out flag
+ *                                  as a starved kernel would (the next call reports it); write 0: forget it.
  *   "rho_lane_particle"    -1..3   density-field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
  *                                  wavevectors per chunk, -1 auto by n_k
  *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles

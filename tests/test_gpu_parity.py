@@ -765,6 +765,59 @@ def test_single_launch_hand_off_under_load_and_reuse():
     assert bad == 0
 
 
+def test_a_sync_timeout_is_reported_once_and_the_workspace_falls_back_to_two_launches():
+    """A single-launch evaluation whose blocks starve each other ends in a time-out (a real one is provoked by
+    `make microbench_persistent_fault`, profiles/r02/fault_injection.txt).  What the library does with it, exercised through the
+    fault-injection tunable: the NEXT call (enqueue or result read) reports CAVMD_ERR_SYNC_TIMEOUT exactly once, enqueues
+    nothing, invalidates the stale result, and from then on the workspace evaluates with two launches -- same bits."""
+    n = 60_001
+    cfg = _random_cfg(n, seed=77, photon_at=n - 1)
+    dev = "cuda"
+    pos = torch.from_numpy(np.concatenate([cfg["position"], cavitymd.state.type_tag_as_double(cfg["typeid"])[:, None]], axis=1)).to(dev)
+    chg = torch.from_numpy(cfg["charge"]).to(dev)
+    img = torch.from_numpy(cfg["image"]).to(dev)
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    L = cfg["box"]
+    ws = _capi.Workspace(n)
+    assert ws.get_tunable("persistent") == -1 and ws.get_tunable("sync_timeout_seen") == 0
+    frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+    want_d = np.array(ws.result().dipole[:])
+    want_f = frc.clone()
+
+    for notice_in in ("compute", "result"):
+        ws.set_tunable("persistent", -1)
+        ws.set_tunable("sync_timeout_seen", 0)
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+        ws.set_tunable("sync_timeout_seen", 1)          # as if that evaluation's kernel had given up
+        frc.fill_(float("nan"))
+        with pytest.raises(_capi.CavmdError) as ei:
+            if notice_in == "compute":
+                ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+            else:
+                ws.result()
+        assert ei.value.status == _capi.CAVMD_ERR_SYNC_TIMEOUT
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(frc).all())              # the reporting call enqueued nothing
+        with pytest.raises(_capi.CavmdError) as ei:
+            ws.result()                                  # the stale result is not handed out as current
+        assert ei.value.status == _capi.CAVMD_ERR_NOT_COMPUTED
+        assert ws.get_tunable("persistent") == 0 and ws.get_tunable("sync_timeout_seen") == 1
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())   # two launches now
+        assert np.array_equal(np.array(ws.result().dipole[:]), want_d)
+        torch.cuda.synchronize()
+        assert torch.equal(frc, want_f)
+
+
+def test_environment_switch_for_shared_gpus(monkeypatch):
+    """CAVMD_PERSISTENT is read by cavmd_create: 0 = two launches (GPUs shared by more processes than fit), 1 = always one."""
+    for env, want in (("0", 0), ("1", 1), ("bogus", -1)):
+        monkeypatch.setenv("CAVMD_PERSISTENT", env)
+        assert _capi.Workspace(1000).get_tunable("persistent") == want
+    monkeypatch.delenv("CAVMD_PERSISTENT")
+    assert _capi.Workspace(1000).get_tunable("persistent") == -1
+
+
 def test_graph_replays_on_changing_data_read_without_sync(ref, oracle_mod):
     """Two captures (single-launch and two-launch), several replays each on data that changes between replays, results read
     straight after graph.replay() with NO device synchronisation by the caller: a captured workspace must not trust the
