@@ -45,7 +45,7 @@ constexpr size_t kChargeTemporalMaxN = 25000000; // charges stay temporal while 
                                                  // 6e6 and 1e7, -5 % at 2e7, tie at 5e7 (profiles/r02/ab_two_launch_knobs.txt)
 constexpr int kPersistBlock = 256;
 constexpr size_t kPersistMaxLds = 156 * 1024; // dynamic LDS of the single-launch kernel (charges of a block's tiles); 160 KiB per CU
-constexpr size_t kPersistSharedLds = 76 * 1024; // default ceiling: two such blocks fit on one CU (two concurrent grids stay resident)
+constexpr size_t kPersistSharedLds = 76 * 1024; // default ceiling: two such blocks (+ 1.7 KiB static each) fit on one CU, so two concurrent grids stay resident
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
 static_assert(sizeof(cavmd_int3) == 12, "int3 layout");

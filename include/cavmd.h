@@ -291,9 +291,10 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces -- by the result read or by the NEXT cavmd_compute_*
  *                                  call, whichever comes first (that call enqueues nothing) -- and the workspace then
  *                                  stays on two launches ("persistent" reads 0, "sync_timeout_seen" reads 1): a grid that
- *                                  was starved once will be again while the GPU is shared the same way.  GPUs shared by
- *                                  more processes than fit (LDS per block x processes > 160 KB; five at N = 1e6, two at
- *                                  2.4e6) should set the environment variable CAVMD_PERSISTENT=0, read by cavmd_create
+ *                                  was starved once will be again while the GPU is shared the same way.  TWO such grids
+ *                                  fit side by side (registers: two 4-wave blocks per CU at 2 particles per lane; LDS: the
+ *                                  auto rule); a GPU shared by three or more processes that each evaluate N > 1024
+ *                                  should set the environment variable CAVMD_PERSISTENT=0, read by cavmd_create
  *                                  (=1 forces the single launch).
  *   "sync_timeout_seen"    0/1     read: 1 after such a time-out.  Write 1: fault-injection hook, raises the time-out flag
  *                                  as a starved kernel would (the next call reports it); write 0: forget it.
