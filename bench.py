@@ -324,6 +324,31 @@ def energy_poll_measurement(cfg, device, frames, steps, warmup):
             "note": "evaluation + energy getters every step (host-visible result block, no memcpy, no stream sync)"}
 
 
+def two_replicas_measurement(cfg, device, frames, steps, warmup):
+    """NOT the headline: two independent replicas of the workload on ONE GPU, one stream each, enqueued alternately by the
+    one host thread.  Each replica's evaluations stay strictly sequential (as in MD); the other replica's kernels fill the
+    gaps the in-launch hand-off and the launch boundaries leave.  Two single-launch grids fit side by side."""
+    rings = [build_ring(cfg, frames, device), build_ring(synthetic.perturb(cfg, 991), frames, device)]
+    streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    nf = frames
+
+    def run(count, first=0):
+        for s in range(first, first + count):
+            for ring, st in zip(rings, streams):
+                ring[s % nf].compute.compute(s, stream=st)
+
+    run(nf)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, first=warmup)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    return {"N": rings[0][0].n, "replicas_on_the_gpu": 2, "evals_per_s_total": 2 * steps / t,
+            "us_per_eval_per_replica": 1e6 * t / steps,
+            "note": "side measurement; the headline value is ONE replica per GPU, as BASELINE.json's north_star prescribes"}
+
+
 def density_field_measurement(cfg, device, n_k=50, kmag=1.0, steps=20, warmup=3):
     """Row f3 side measurement: rho(k) for 50 Fibonacci-sphere wavevectors (the reference tracker's default)."""
     from cavitymd import observables
@@ -447,6 +472,8 @@ def main():
             extras["bussi_thermostat_step_1e6"] = thermostat_measurement(n, ctx.device)
             extras["1e6_energy_poll_every_step"] = energy_poll_measurement(cfg, ctx.device, spec["frames"], spec["steps"],
                                                                            spec["warmup"])
+            extras["1e6_two_replicas_two_streams"] = two_replicas_measurement(cfg, ctx.device, spec["frames"], spec["steps"],
+                                                                              spec["warmup"])
             line["extras"] = extras
     rank = ctx.rank
     replicas.shutdown(ctx)
