@@ -89,6 +89,7 @@ struct cavmd_workspace
     // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
     unsigned long long* d_granules = nullptr;
     unsigned* d_epoch = nullptr;
+    bool sync_state_dirty = false;  // a starved evaluation may have left records or counts behind: wipe before the next single launch
     bool sync_timeout_seen = false; // an inter-workgroup wait of the single-launch kernel gave up once: two launches from then on
     bool captured = false; // some evaluation was enqueued into a stream capture: the host-side flag protocol is off
     // profiling
@@ -408,11 +409,11 @@ int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
     if (e == hipSuccess) // tag 0 = never valid
         e = hipMemset(ws->d_granules, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid);
     if (e == hipSuccess)
-        e = hipMalloc((void**)&ws->d_epoch, sizeof(unsigned));
+        e = hipMalloc((void**)&ws->d_epoch, 2 * sizeof(unsigned));
     if (e == hipSuccess)
     {
-        const unsigned one = 1;
-        e = hipMemcpy(ws->d_epoch, &one, sizeof(one), hipMemcpyHostToDevice);
+        const unsigned init[2] = {1u, 0u}; // first tag; no block has given up
+        e = hipMemcpy(ws->d_epoch, init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess)
         e = allow_large_lds();
@@ -473,19 +474,30 @@ int cavmd_destroy(cavmd_workspace* ws)
 
 namespace
 {
-// A single-launch evaluation whose blocks were not resident together ends in a time-out (NaN forces, sync_error raised in
-// the host-visible block).  Whoever notices first -- the next enqueue or the result read -- turns the single-launch path
-// off for this workspace for good: the condition that starved the grid (other grids holding the CUs' LDS) is a property
-// of the deployment, not of one step, and the two-launch path does not depend on residency.
-bool consume_sync_timeout(cavmd_workspace* ws)
+// A single-launch evaluation whose blocks were not resident together (other grids held the CUs) either got completed by its
+// last block alone (kSyncRepaired: results valid, it just took a second) or failed (kSyncFailed: NaN forces) -- see the
+// bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- turns the
+// single-launch path off for this workspace for good: what starved the grid is a property of the deployment, not of one
+// step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
+unsigned consume_sync_timeout(cavmd_workspace* ws)
 {
     if (!ws->h_result || !__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
-        return false;
+        return 0;
+    // kSyncFailed is provisional while the kernel runs (the first block that gives up raises it, the last one may still
+    // complete the evaluation): the verdict is the flag once the stream has drained.  A stream that is being captured cannot
+    // be waited for; the provisional value then counts.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ws->last_stream == nullptr || hipStreamIsCapturing(ws->last_stream, &cap) != hipSuccess
+        || cap == hipStreamCaptureStatusNone)
+        (void)hipStreamSynchronize(ws->last_stream);
+    const unsigned verdict = __atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE);
     __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
     ws->sync_timeout_seen = true;
+    ws->sync_state_dirty = true;
     ws->persistent = 0;
-    ws->computed = false; // the result block still holds the evaluation BEFORE the failed one
-    return true;
+    if (verdict != kSyncRepaired)
+        ws->computed = false; // the result block still holds the evaluation BEFORE the failed one
+    return verdict == kSyncRepaired ? kSyncRepaired : kSyncFailed;
 }
 } // namespace
 
@@ -504,9 +516,9 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         return CAVMD_ERR_CAPACITY;
     if (!params_ok(params))
         return CAVMD_ERR_BAD_PARAMS;
-    // an EARLIER evaluation timed out (its forces are NaN) and nobody read the result since: report it here, nothing is
-    // enqueued by this call; the next call takes the two-launch path
-    if (consume_sync_timeout(ws))
+    // an EARLIER evaluation was starved and nobody read the result since.  Failed (its forces are NaN): report it here,
+    // nothing is enqueued by this call.  Repaired: nothing to report.  Either way two launches from now on.
+    if (consume_sync_timeout(ws) == kSyncFailed)
         return CAVMD_ERR_SYNC_TIMEOUT;
 
     hipStream_t stream = (hipStream_t)stream_;
@@ -586,6 +598,13 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         if (resident && (ws->persistent > 0
                          || (ws->persistent < 0 && slots <= cap_slots && lds <= kPersistSharedLds && persistent_auto(N))))
         {
+            if (ws->sync_state_dirty)
+            {
+                // re-enabled after a starved evaluation: records or give-up counts of that launch must not meet this one
+                CAVMD_HIP_TRY(hipMemsetAsync(ws->d_granules, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid, stream));
+                CAVMD_HIP_TRY(hipMemsetAsync(ws->d_epoch + 1, 0, sizeof(unsigned), stream));
+                ws->sync_state_dirty = false;
+            }
             ws->sequence += 1;
             const AosInputT<2> inx {in.pos2, in.charge, in.image};
             const SyncState sync {ws->d_granules, ws->d_epoch};
@@ -831,9 +850,10 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
                 return (int)q;
         }
     }
-    // The evaluation failed loudly (NaN forces).  The result block still holds the PREVIOUS evaluation: it is invalidated,
-    // so that a second read reports "nothing computed" instead of handing that out as if it were current.
-    if (consume_sync_timeout(ws))
+    // A starved evaluation that failed (NaN forces): the result block still holds the PREVIOUS evaluation, which is
+    // invalidated so that a second read reports "nothing computed" instead of handing that out as if it were current.
+    // One that its last block completed has published its result like any other.
+    if (consume_sync_timeout(ws) == kSyncFailed)
         return CAVMD_ERR_SYNC_TIMEOUT;
     memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
     return CAVMD_OK;
@@ -1273,12 +1293,13 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
     }
     if (!strcmp(name, "sync_timeout_seen"))
     {
-        // fault-injection hook (value 1): raises the time-out flag of the host-visible block exactly as a starved single-launch
-        // kernel would, so that callers and tests can exercise their handling; 0 forgets a time-out seen earlier
-        if (value < 0 || value > 1)
+        // fault-injection hook: raises the flag of the host-visible block as a starved single-launch kernel would -- 1: the
+        // evaluation failed, 2: its last block completed it -- so that callers and tests can exercise their handling; 0 forgets
+        // a time-out seen earlier
+        if (value < 0 || value > 2)
             return CAVMD_ERR_INVALID_VALUE;
         if (value)
-            __atomic_store_n(&ws->h_result->sync_error, 1u, __ATOMIC_RELEASE);
+            __atomic_store_n(&ws->h_result->sync_error, value == 2 ? kSyncRepaired : kSyncFailed, __ATOMIC_RELEASE);
         else
             ws->sync_timeout_seen = false;
         return CAVMD_OK;
@@ -1382,7 +1403,7 @@ const char* cavmd_error_string(int status)
     case CAVMD_ERR_NOT_COMPUTED:
         return "no evaluation has been enqueued on this workspace yet";
     case CAVMD_ERR_SYNC_TIMEOUT:
-        return "the single-launch kernel's inter-workgroup wait timed out (its blocks were not resident together); "
+        return "a single-launch evaluation was starved (its workgroups were not resident together) and could not be completed; "
                "forces of that evaluation are NaN";
     default:
         break;

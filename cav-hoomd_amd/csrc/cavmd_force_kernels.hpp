@@ -472,7 +472,7 @@ struct HostResult
 {
     cavmd_result result;
     uint64_t ready;
-    unsigned sync_error; // raised by the single-launch kernel when its bounded inter-workgroup wait timed out
+    unsigned sync_error; // single-launch kernel, starved evaluation: kSyncFailed / kSyncRepaired (cavmd_persistent_kernel.hpp)
     unsigned pad;
 };
 __device__ __forceinline__ void publish_to_host(HostResult* __restrict__ host, const Scalars& sc, unsigned N,

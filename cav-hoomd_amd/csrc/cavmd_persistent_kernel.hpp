@@ -40,7 +40,11 @@ namespace cavmd
 {
 
 constexpr int kGranulesPerRecord = 2 * kNumPartDoubles + kNumPartInts; // 9 doubles as 18 halves + lmin + lcnt
-constexpr unsigned kSpinLimit = 4000000;                               // ~ seconds; a healthy wait is microseconds
+#ifndef CAVMD_SPIN_LIMIT
+#define CAVMD_SPIN_LIMIT 1000000 // poll rounds of a bounded wait: ~0.4 s; a healthy wait is microseconds
+#endif
+constexpr unsigned kSpinLimit = CAVMD_SPIN_LIMIT;
+constexpr unsigned kRepairRounds = 4096; // the last block of a starved evaluation finds every record in place: no real wait
 
 constexpr int kGroup = 16;           // blocks per first-level group = lanes of a DPP row
 constexpr unsigned kMaxPersistGrid = kGroup * kGroup;
@@ -52,8 +56,12 @@ struct SyncState
 {
     unsigned long long* granules; // kMaxPersistGrid block records, then kGroupCopies x kGroup group records; a record is
                                   // kGranulesPerRecord granules {tag << 32 | value} = 160 contiguous bytes
-    unsigned* epoch;              // tag of the next evaluation (never 0)
+    unsigned* epoch;              // epoch[0]: tag of the next evaluation (never 0); epoch[1]: blocks of the running evaluation
+                                  // that gave up waiting (0 outside a starved evaluation)
 };
+// HostResult::sync_error
+constexpr unsigned kSyncFailed = 1u;   // some block gave up and nobody could complete the evaluation: its forces hold NaN
+constexpr unsigned kSyncRepaired = 2u; // every block gave up; the last one completed the whole evaluation alone: results valid
 
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long* g)
 {
@@ -68,6 +76,17 @@ __device__ __forceinline__ void record_to_lds(unsigned* s_rec, const Accum& a)
     sd[6] = a.sx; sd[7] = a.sy; sd[8] = a.sz;
     s_rec[2 * kNumPartDoubles] = (unsigned)a.lmin;
     s_rec[2 * kNumPartDoubles + 1] = (unsigned)a.lcnt;
+}
+
+__device__ __forceinline__ void record_from_lds(const unsigned* w, Accum& o)
+{
+    o.hx = __hiloint2double((int)w[1], (int)w[0]);   o.lx = __hiloint2double((int)w[3], (int)w[2]);
+    o.hy = __hiloint2double((int)w[5], (int)w[4]);   o.ly = __hiloint2double((int)w[7], (int)w[6]);
+    o.hz = __hiloint2double((int)w[9], (int)w[8]);   o.lz = __hiloint2double((int)w[11], (int)w[10]);
+    o.sx = __hiloint2double((int)w[13], (int)w[12]); o.sy = __hiloint2double((int)w[15], (int)w[14]);
+    o.sz = __hiloint2double((int)w[17], (int)w[16]);
+    o.lmin = (int)w[18];
+    o.lcnt = (int)w[19];
 }
 
 // Wave 0 (all 64 lanes active): the Accum held by lane 0 -> record `rec` of `copies` consecutive copies of a slab of
@@ -98,7 +117,7 @@ __device__ __forceinline__ void publish_record(unsigned long long* slab, unsigne
 // were complete (wave-uniform).
 __device__ __forceinline__ bool gather_records(const unsigned long long* slab, unsigned first, unsigned count, unsigned tag,
                                                unsigned* s_words, Accum& o, unsigned max_rounds, int own_slot,
-                                               const Accum& own)
+                                               const Accum& own, const unsigned* giveups = nullptr)
 {
     constexpr int ROUNDS = (kGroup * kGranulesPerRecord + kWave - 1) / kWave; // 5
     const unsigned lane = threadIdx.x;
@@ -108,7 +127,9 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
     for (unsigned spins = 1;; ++spins)
     {
         // all five loads in flight together (clamped index instead of a branch per load: hipcc otherwise waits for each
-        // load before it issues the next, five round trips per round)
+        // load before it issues the next, five round trips per round); with them, where asked for, the count of blocks that
+        // have given up on this evaluation: once one has, nobody may complete on its own any more (see the bail path)
+        const unsigned gone = giveups ? __hip_atomic_load(giveups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
         for (int j = 0; j < ROUNDS; ++j)
         {
@@ -123,6 +144,8 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
             const bool mine = own_slot >= 0 && (i < total ? i : total - 1) / kGranulesPerRecord == (unsigned)own_slot;
             ok = ok && (mine || (unsigned)(x[j] >> 32) == tag);
         }
+        if (gone != 0)
+            return false;
         if (__all(ok))
             break;
         if (spins >= max_rounds)
@@ -137,16 +160,7 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
     if (own_slot >= 0 && lane == 0)
         record_to_lds(s_words + own_slot * kGranulesPerRecord, own);
     if (lane < count)
-    {
-        const unsigned* w = s_words + lane * kGranulesPerRecord;
-        o.hx = __hiloint2double((int)w[1], (int)w[0]);   o.lx = __hiloint2double((int)w[3], (int)w[2]);
-        o.hy = __hiloint2double((int)w[5], (int)w[4]);   o.ly = __hiloint2double((int)w[7], (int)w[6]);
-        o.hz = __hiloint2double((int)w[9], (int)w[8]);   o.lz = __hiloint2double((int)w[11], (int)w[10]);
-        o.sx = __hiloint2double((int)w[13], (int)w[12]); o.sy = __hiloint2double((int)w[15], (int)w[14]);
-        o.sz = __hiloint2double((int)w[17], (int)w[16]);
-        o.lmin = (int)w[18];
-        o.lcnt = (int)w[19];
-    }
+        record_from_lds(s_words + lane * kGranulesPerRecord, o);
     return true;
 }
 
@@ -208,6 +222,14 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     const unsigned G = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
 
     CAVMD_PSTAMP(0);
+#ifdef CAVMD_FAULT_LATE_BLOCK // microbench only: this block starts late, as if its CU had been held by another grid
+    if (b == CAVMD_FAULT_LATE_BLOCK)
+    {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)CAVMD_FAULT_LATE_TICKS)
+            __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     // this evaluation's tag, and the speculative photon row (the driver appends the photon last)
     const unsigned tag = __hip_atomic_load(st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         {
             // A grid of at most 16 blocks (N up to ~4000) is ONE group: every block gathers the block records itself, its own
             // from registers -- one hop instead of two, and the same fold (the second level would only add zeros).
-            ok = gather_records(block_slab, 0, G, tag, s_words, o, kSpinLimit, (int)b, acc);
+            ok = gather_records(block_slab, 0, G, tag, s_words, o, kSpinLimit, (int)b, acc, st.epoch + 1);
             CAVMD_PSTAMP(7);
         }
         else
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             }
             CAVMD_PSTAMP(7);
             ok = gather_records(group_slab + (size_t)(b % kGroupCopies) * kGroup * kGranulesPerRecord, 0,
-                                (G + kGroup - 1) / kGroup, tag, s_words, o, kSpinLimit, -1, acc)
+                                (G + kGroup - 1) / kGroup, tag, s_words, o, kSpinLimit, -1, acc, st.epoch + 1)
                  && ok;
         }
         t.merge(o);
@@ -313,17 +335,12 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             s_mi[0] = sc.photon;
             s_mi[1] = sc.nL;
             s_mi[2] = !ok;
-            if (!ok)
-                __hip_atomic_store(&res_host->sync_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (publisher)
+            if (publisher && ok)
             {
                 // every block has published, hence read the epoch: advance it for the next launch (0 is never a tag)
                 __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ok)
-                {
-                    write_result(res, sc, N, G, sequence);
-                    publish_to_host(res_host, sc, N, G, sequence);
-                }
+                write_result(res, sc, N, G, sequence);
+                publish_to_host(res_host, sc, N, G, sequence);
             }
         }
     }
@@ -339,14 +356,14 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     // ---- phase 2: forces of this block's own tiles, charges from LDS ------------------------------------------------------
     const size_t nchunks = 2 * (size_t)N;
     const v2d zero = {0.0, 0.0};
-    if (bad || m.photon < 0 || m.nL > 1)
-    {
-        // time-out (NaN: loud), no photon (zeros, src/CavityForceCompute.cc:145-156), or several L-typed particles (the
-        // type tag has to be read: only non-L particles get a molecular force, :190-191) -- all rare, all from global memory
+    // The slow map, all from global memory: tiles t0, t0 + step, ...; NaN everywhere (poison), or the general rule -- no photon:
+    // zeros (src/CavityForceCompute.cc:145-156); several L-typed particles: the type tag has to be read, only non-L particles
+    // get a molecular force (:190-191).
+    auto slow_map = [&](unsigned t0, unsigned step, bool poison, const MapScalars& ms) {
         const double nan = __builtin_nan("");
         const double ng = -prm.g;
         const bool odd = tid & 1;
-        for (unsigned t = b; (size_t)t * TILE < N; t += G)
+        for (unsigned t = t0; (size_t)t * TILE < N; t += step)
         {
 #pragma unroll
             for (int u = 0; u < MU; ++u)
@@ -355,21 +372,104 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
                 if (k >= nchunks)
                     continue;
                 v2d v = zero;
-                if (bad)
+                if (poison)
                     v = (v2d) {nan, nan};
-                else if (m.photon >= 0)
+                else if (ms.photon >= 0)
                 {
                     const size_t p = k >> 1;
                     const int ptag = __double2loint(in.pos2[2 * p + 1].y);
                     const double s = ng * in.charge[p];
-                    v = (v2d) {s * m.Dqx, s * m.Dqy};
+                    v = (v2d) {s * ms.Dqx, s * ms.Dqy};
                     v = (odd || ptag == L_typeid) ? zero : v;
-                    if (p == (size_t)m.photon)
-                        v = odd ? (v2d) {m.Fz, 0.0} : (v2d) {m.Fx, m.Fy};
+                    if (p == (size_t)ms.photon)
+                        v = odd ? (v2d) {ms.Fz, 0.0} : (v2d) {ms.Fx, ms.Fy};
                 }
                 store_chunk<NT_STORE>(force2 + k, v);
             }
         }
+    };
+    if (bad)
+    {
+        // ---- this block gave up waiting: some block of the grid was not resident (other grids hold the CUs) -----------------
+        // Loud by default: NaN over the block's own tiles and the failure flag.  Then the block LEAVES, which frees its CU for
+        // the blocks that have not started.  Those find no group totals (the group leaders have left), give up in turn -- and
+        // the last one to do so, which knows from the count that every block has published its record, completes the whole
+        // evaluation alone: same records, same fold, same bits; a millisecond instead of microseconds, once, after which the
+        // host keeps this workspace on two launches.  If some blocks did get the total while others gave up (a race of
+        // microseconds after a wait of a third of a second), the count never completes and the evaluation stays failed.
+        __shared__ unsigned s_last;
+        slow_map(b, G, true, m);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0)
+        {
+            __hip_atomic_store(&res_host->sync_error, kSyncFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_last = __hip_atomic_fetch_add(st.epoch + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
+        __shared__ __attribute__((aligned(8))) unsigned s_groups[kGroup * kGranulesPerRecord];
+        if (tid < kWave)
+        {
+            bool ok = true;
+            Accum o, t;
+            if (G <= (unsigned)kGroup)
+                ok = gather_records(block_slab, 0, G, tag, s_words, o, kRepairRounds, -1, acc);
+            else
+            {
+                const unsigned ngroups = (G + kGroup - 1) / kGroup;
+                for (unsigned g = 0; g < ngroups; ++g)
+                {
+                    Accum o1, t1;
+                    ok = gather_records(block_slab, g * kGroup, min(G - g * kGroup, (unsigned)kGroup), tag, s_words, o1,
+                                        kRepairRounds, -1, acc)
+                         && ok;
+                    t1.merge(o1);
+                    t1 = row_fold16(t1);
+                    if (tid == 0)
+                        record_to_lds(s_groups + g * kGranulesPerRecord, t1);
+                }
+                // same wave: LDS operations complete in order, no barrier needed
+                if (tid < ngroups)
+                    record_from_lds(s_groups + tid * kGranulesPerRecord, o);
+            }
+            t.merge(o);
+            const Accum tot = row_fold16(t);
+            const Scalars sc = scalars_from_total<AosInputT<2>>(tot, guess, in, N, Lx, Ly, Lz, prm, true);
+            if (tid == 0)
+            {
+                s_m[0] = sc.Dq[0]; s_m[1] = sc.Dq[1]; s_m[2] = sc.f[0]; s_m[3] = sc.f[1]; s_m[4] = sc.f[2];
+                s_mi[0] = sc.photon;
+                s_mi[1] = sc.nL;
+                s_mi[2] = !ok;
+                if (ok)
+                {
+                    // the verdict first, the result's ready flag (a release) after it: a host that sees the result sees "repaired"
+                    __hip_atomic_store(&res_host->sync_error, kSyncRepaired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    write_result(res, sc, N, G, sequence);
+                    publish_to_host(res_host, sc, N, G, sequence);
+                }
+            }
+        }
+        __syncthreads();
+        MapScalars mr;
+        mr.Dqx = s_m[0]; mr.Dqy = s_m[1]; mr.Fx = s_m[2]; mr.Fy = s_m[3]; mr.Fz = s_m[4];
+        mr.photon = s_mi[0];
+        mr.nL = s_mi[1];
+        if (!s_mi[2])
+            slow_map(0, 1, false, mr); // over the other blocks' NaN: their stores were fenced before they were counted
+        if (tid == 0)
+        {
+            // every block has read the epoch and been counted: leave both ready for the next evaluation
+            __hip_atomic_store(st.epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (m.photon < 0 || m.nL > 1)
+    {
+        slow_map(b, G, false, m); // rare, from global memory
         return;
     }
 

@@ -91,9 +91,9 @@ int main(int argc, char** argv)
     CHECK(hipMalloc((void**)&d_hres, sizeof(HostResult)));
     CHECK(hipMalloc((void**)&d_gran, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
     CHECK(hipMemset(d_gran, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
-    CHECK(hipMalloc((void**)&d_epoch, 4));
-    const unsigned one = 1;
-    CHECK(hipMemcpy(d_epoch, &one, 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc((void**)&d_epoch, 8));
+    const unsigned epoch_init[2] = {1u, 0u};
+    CHECK(hipMemcpy(d_epoch, epoch_init, 8, hipMemcpyHostToDevice));
     Partials part {d_part, d_ipart, max_parts};
     SyncState sync {d_gran, d_epoch};
     const double L = 215.4;
@@ -116,31 +116,62 @@ int main(int argc, char** argv)
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
 
-#ifdef CAVMD_FAULT_SILENT_BLOCK
+#if defined(CAVMD_FAULT_SILENT_BLOCK) || defined(CAVMD_FAULT_LATE_BLOCK)
     {
-        // fault injection: one launch in which a block stays silent.  Expected: the kernel ends after its bounded spins
-        // (seconds, not forever), sync_error is raised, every force entry is NaN.
-        std::vector<double> h_f(4 * N, 0.0);
-        CHECK(hipMemset(d_hres, 0, sizeof(HostResult)));
-        hipEvent_t a, b2;
-        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b2));
+        // Fault injection, one launch.
+        //   silent block: a block never publishes its record.  Expected: every block gives up after its bounded wait, the last
+        //     one cannot complete the evaluation either (a record is missing): the kernel ends, sync_error = 1 (failed), no
+        //     result published, every force entry NaN.
+        //   late block: a block starts after all the others have given up (as if its CU had been held by another grid).
+        //     Expected: it gives up in turn, is the last to do so and completes the whole evaluation alone: sync_error = 2
+        //     (repaired), result published, forces and dipole bit for bit those of the two-launch path.
+        std::vector<double> h_f(4 * N, 0.0), h_want(4 * N, 0.0);
         const unsigned g1 = grid(N, 256 * unroll, 1);
         const size_t tile = 256 * unroll;
         const size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
+        // the two-launch path on the same frame: what a repaired evaluation has to reproduce
+        if (unroll == 2)
+            hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, 256, 2, false>), dim3(g1), dim3(256), 0, st, in1(0), n, L, L, L, 2, part);
+        else
+            hipLaunchKernelGGL((dipole_partials_kernel<AosInputT<1>, 256, 1, false>), dim3(g1), dim3(256), 0, st, in1(0), n, L, L, L, 2, part);
+        hipLaunchKernelGGL((force_map_aos_fused_kernel<256, 4, false>), dim3(grid(2 * N, 1024, 2)), dim3(256), 0, st, in0(0), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[0], false);
+        CHECK(hipDeviceSynchronize());
+        cavmd_result want_res; CHECK(hipMemcpy(&want_res, d_res, sizeof(want_res), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(h_want.data(), d_frc[0], 32 * N, hipMemcpyDeviceToHost));
+        CHECK(hipMemset(d_frc[0], 0x5A, 32 * N));
+        CHECK(hipMemset(d_hres, 0, sizeof(HostResult)));
+        CHECK(hipMemset(d_res, 0, sizeof(cavmd_result)));
+        hipEvent_t a, b2;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b2));
         CHECK(hipEventRecord(a, st));
         if (unroll == 2)
-            hipLaunchKernelGGL((cavity_persistent_kernel<256, 2, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 2, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
         else
-            hipLaunchKernelGGL((cavity_persistent_kernel<256, 1, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 1, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
         CHECK(hipEventRecord(b2, st));
         CHECK(hipEventSynchronize(b2));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b2));
         HostResult hr; CHECK(hipMemcpy(&hr, d_hres, sizeof(hr), hipMemcpyDeviceToHost));
+        cavmd_result got_res; CHECK(hipMemcpy(&got_res, d_res, sizeof(got_res), hipMemcpyDeviceToHost));
+        unsigned after[2]; CHECK(hipMemcpy(after, d_epoch, 8, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(h_f.data(), d_frc[0], 32 * N, hipMemcpyDeviceToHost));
-        size_t nan = 0; for (double v : h_f) nan += (v != v);
-        printf("fault injection (block %d silent, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu of %zu\n",
-               CAVMD_FAULT_SILENT_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, h_f.size());
-        return (hr.sync_error == 1 && nan == h_f.size() && hr.ready == 0) ? 0 : 1;
+        size_t nan = 0, differ = 0;
+        for (size_t i = 0; i < h_f.size(); ++i) { nan += (h_f[i] != h_f[i]); differ += memcmp(&h_f[i], &h_want[i], 8) != 0; }
+        const bool same_dipole = memcmp(got_res.dipole, want_res.dipole, sizeof(got_res.dipole)) == 0
+                                 && memcmp(hr.result.dipole, want_res.dipole, sizeof(got_res.dipole)) == 0;
+#ifdef CAVMD_FAULT_SILENT_BLOCK
+        (void)differ; (void)same_dipole;
+        printf("fault injection (block %d silent, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu of %zu, epoch %u, give-up count left %u\n",
+               CAVMD_FAULT_SILENT_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, h_f.size(), after[0], after[1]);
+        // (with at most 16 blocks every block gathers the block records itself: the silent block, which has its own record in
+        // registers, completes its own tile and leaves; the others can never be complete -- a stuck give-up count and an epoch
+        // that was not advanced are what the host wipes before it would use the single launch again)
+        return (hr.sync_error == 1 && nan >= h_f.size() - 4 * (size_t)tile && hr.ready == 0) ? 0 : 1;
+#else
+        printf("fault injection (block %d late, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu, force entries differing from the two-launch path %zu of %zu, dipole identical %d, epoch %u, give-up count left %u\n",
+               CAVMD_FAULT_LATE_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, differ, h_f.size(), (int)same_dipole, after[0], after[1]);
+        return (hr.sync_error == 2 && nan == 0 && differ == 0 && hr.ready == 7 && same_dipole && after[0] == 2 && after[1] == 0) ? 0 : 1;
+#endif
     }
 #endif
     std::vector<Variant> V;

@@ -78,9 +78,9 @@ extern "C" {
 #define CAVMD_ERR_CAPACITY (-3)      /* N exceeds the capacity the workspace was created for */
 #define CAVMD_ERR_BAD_PARAMS (-4)    /* K == 0 or non-finite parameters */
 #define CAVMD_ERR_NOT_COMPUTED (-5)  /* results requested before any cavmd_compute_* call */
-#define CAVMD_ERR_SYNC_TIMEOUT (-6)  /* the single-launch kernel's bounded inter-workgroup wait gave up (its blocks were
-                                        not resident together, e.g. CUs held by a never-ending foreign kernel); that
-                                        evaluation's forces are NaN.  Returned by cavmd_result_read / cavmd_energies. */
+#define CAVMD_ERR_SYNC_TIMEOUT (-6)  /* a starved single-launch evaluation that could not be completed (see the "persistent"
+                                        tunable): that evaluation's forces are NaN.  Returned by cavmd_result_read /
+                                        cavmd_energies or by the next cavmd_compute_* call, whichever comes first. */
 
 /* ---- layouts (bit-compatible with HOOMD-blue's Scalar4 / int3 in a double-precision build) -- */
 typedef struct cavmd_double4
@@ -286,18 +286,25 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  charges kept in LDS): 1 whenever the grid is <= 256 blocks, 0 never (two launches),
  *                                  -1 auto: while a block's charges take at most half a CU's LDS (N <~ 2.4e6), so that two
  *                                  concurrent grids (other streams, other processes on the same GPU) can both be resident.
- *                                  The kernel's workgroups wait for each other inside the launch: they must all be
- *                                  resident together; every wait is bounded and a give-up is reported as
- *                                  CAVMD_ERR_SYNC_TIMEOUT with NaN forces -- by the result read or by the NEXT cavmd_compute_*
- *                                  call, whichever comes first (that call enqueues nothing) -- and the workspace then
- *                                  stays on two launches ("persistent" reads 0, "sync_timeout_seen" reads 1): a grid that
- *                                  was starved once will be again while the GPU is shared the same way.  TWO such grids
- *                                  fit side by side (registers: two 4-wave blocks per CU at 2 particles per lane; LDS: the
- *                                  auto rule); a GPU shared by three or more processes that each evaluate N > 1024
- *                                  should set the environment variable CAVMD_PERSISTENT=0, read by cavmd_create
- *                                  (=1 forces the single launch).
- *   "sync_timeout_seen"    0/1     read: 1 after such a time-out.  Write 1: fault-injection hook, raises the time-out flag
- *                                  as a starved kernel would (the next call reports it); write 0: forget it.
+ *                                  The kernel's workgroups wait for each other inside the launch, which needs them all
+ *                                  resident together.  TWO such grids fit side by side (registers: two 4-wave blocks per CU
+ *                                  at 2 particles per lane; LDS: the auto rule); when more grids, or foreign kernels,
+ *                                  hold the CUs, part of a grid cannot start.  Every wait is bounded (~0.4 s): workgroups
+ *                                  that give up poison their share of the forces with NaN and LEAVE, which lets the rest
+ *                                  of the grid start; the last workgroup to give up finds every partial in place and
+ *                                  completes the whole evaluation alone (same fold, same bits, ~1 ms).  Such an
+ *                                  evaluation is late but valid and is not reported as an error.  If it cannot be
+ *                                  completed (not observed outside fault injection) the forces stay NaN and the result
+ *                                  read or the NEXT cavmd_compute_* call, whichever comes first, returns
+ *                                  CAVMD_ERR_SYNC_TIMEOUT (that call enqueues nothing).  In both cases the workspace
+ *                                  stays on two launches afterwards ("persistent" reads 0, "sync_timeout_seen" reads 1):
+ *                                  a grid that was starved once will be again while the GPU is shared the same way.  A
+ *                                  GPU known to be shared by three or more processes that each evaluate N > 1024 can
+ *                                  skip the one slow step with the environment variable CAVMD_PERSISTENT=0, read by
+ *                                  cavmd_create (=1 forces the single launch).
+ *   "sync_timeout_seen"    0..2    read: 1 after a starved evaluation.  Write: fault-injection hook, raises the flag of
+ *                                  the host-visible block as a starved kernel would -- 1: failed, 2: completed by its last
+ *                                  workgroup (the next call acts on it); write 0: forget it.
  *   "rho_lane_particle"    -1..3   density-field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
  *                                  wavevectors per chunk, -1 auto by n_k
  *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Several processes evaluating on ONE GPU at the same time: does the single-launch kernel's residency requirement hold up?
 
-    python scripts/multi_process_residency.py <processes> <n_molecular> <evaluations> [persistent]
+    python scripts/multi_process_residency.py <processes> <n_molecular> <evaluations> [persistent] [verify]
+
+"verify": every evaluation writes into a force array poisoned with NaN just before and is compared bit for bit with the
+first one on the device (two extra small kernels per step, no host synchronisation) -- that is how the one starved
+evaluation, whichever it is, gets checked.
 
 The parent never touches the GPU; it starts <processes> children (fresh interpreters), which build their own system,
 wait for a common start time and then evaluate back to back, reading the result every 25 evaluations (that is where a
@@ -17,7 +21,7 @@ import time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
-def child(n_mol, evals, persistent, start_at):
+def child(n_mol, evals, persistent, start_at, verify):
     sys.path.insert(0, os.path.join(ROOT, "cav-hoomd_amd"))
     import numpy as np
     import torch
@@ -42,13 +46,19 @@ def child(n_mol, evals, persistent, start_at):
     ws.compute_hoomd(*args)
     want = np.array(ws.result().dipole[:])
     torch.cuda.synchronize()
+    want_f = frc.clone()
+    force_mismatches = torch.zeros((), dtype=torch.int64, device=dev)
     while time.time() < start_at:
         time.sleep(0.001)
     timeouts = wrong = done = 0
     t0 = time.perf_counter()
     for it in range(evals):
         try:
+            if verify:
+                frc.fill_(float("nan"))
             ws.compute_hoomd(*args)
+            if verify:
+                force_mismatches += (frc.view(torch.int64) != want_f.view(torch.int64)).any()
             done += 1
             if it % 25 == 24:
                 wrong += int(not np.array_equal(np.array(ws.result().dipole[:]), want))
@@ -59,21 +69,24 @@ def child(n_mol, evals, persistent, start_at):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"pid": os.getpid(), "N": n, "evals_per_s": done / dt, "timeouts": timeouts, "wrong_results": wrong,
+                      "evaluations_with_wrong_forces": int(force_mismatches.item()) if verify else None,
                       "persistent_after": ws.get_tunable("persistent"),
                       "sync_timeout_seen": ws.get_tunable("sync_timeout_seen")}), flush=True)
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(int(sys.argv[2]), int(sys.argv[3]), None if sys.argv[4] == "auto" else int(sys.argv[4]), float(sys.argv[5]))
+        child(int(sys.argv[2]), int(sys.argv[3]), None if sys.argv[4] == "auto" else int(sys.argv[4]), float(sys.argv[5]),
+              sys.argv[6] == "verify")
         return
     procs, n_mol, evals = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     persistent = sys.argv[4] if len(sys.argv) > 4 else "auto"
+    verify = "verify" if len(sys.argv) > 5 and sys.argv[5] == "verify" else "plain"
     if procs > 6:
         raise SystemExit("at most 6 processes on the card")
     start_at = time.time() + 60.0 + 20.0 * procs  # children need to import torch and build their systems first
     kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(n_mol), str(evals), persistent,
-                              repr(start_at)]) for _ in range(procs)]
+                              repr(start_at), verify]) for _ in range(procs)]
     rc = 0
     deadline = time.time() + 600
     for k in kids:
@@ -82,7 +95,7 @@ def main():
         except subprocess.TimeoutExpired:
             k.kill()
             rc |= 1
-    print(f"# {procs} processes, n_molecular={n_mol}, {evals} evaluations each, persistent={persistent}: rc={rc}")
+    print(f"# {procs} processes, n_molecular={n_mol}, {evals} evaluations each, persistent={persistent}, {verify}: rc={rc}")
     sys.exit(rc)
 
 
