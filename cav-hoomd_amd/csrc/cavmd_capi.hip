@@ -89,6 +89,9 @@ struct cavmd_workspace
     // single-launch evaluation: granule slab + epoch word (device), see cavmd_persistent_kernel.hpp
     unsigned long long* d_granules = nullptr;
     unsigned* d_epoch = nullptr;
+    int debug_spin_limit = 0;     // tests: poll rounds of the single-launch kernel's bounded waits (0 = kSpinLimit)
+    int debug_late_block = -1;    // tests: this block of the single-launch grid starts debug_late_ticks late (-1 = none)
+    int debug_late_ticks = 0;     //        (100 MHz wall clock)
     bool sync_state_dirty = false;  // a starved evaluation may have left records or counts behind: wipe before the next single launch
     bool sync_timeout_seen = false; // an inter-workgroup wait of the single-launch kernel gave up once: two launches from then on
     bool captured = false; // some evaluation was enqueued into a stream capture: the host-side flag protocol is off
@@ -286,6 +289,13 @@ hipError_t allow_large_lds()
         CAVMD_ALLOW(2, 1)
         CAVMD_ALLOW(2, 2)
 #undef CAVMD_ALLOW
+        // the fault-injection instantiations (tests: "debug_late_block")
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, 1, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, 2, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
         return e;
     }();
     return once;
@@ -607,11 +617,24 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
             }
             ws->sequence += 1;
             const AosInputT<2> inx {in.pos2, in.charge, in.image};
-            const SyncState sync {ws->d_granules, ws->d_epoch};
+            const SyncState sync {ws->d_granules, ws->d_epoch, ws->debug_spin_limit > 0 ? (unsigned)ws->debug_spin_limit : kSpinLimit,
+                                  ws->debug_late_block, (unsigned)ws->debug_late_ticks};
 #define CAVMD_LAUNCH_PERSIST(UNR, NTS)                                                                               \
     st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, UNR, NTS>, g1, kPersistBlock, inx, n, Lx, Ly, Lz, \
                        dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2, (unsigned)lds_slots, balanced);
-            if (unroll == 2)
+            if (ws->debug_late_block >= 0)
+            {
+                // fault injection (tests): one block starts late -> the grid starves itself and has to be repaired
+                if (unroll == 2)
+                    st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, 2, 0, true>, g1, kPersistBlock, inx, n, Lx, Ly,
+                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2,
+                                       (unsigned)lds_slots, balanced);
+                else
+                    st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, 1, 0, true>, g1, kPersistBlock, inx, n, Lx, Ly,
+                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2,
+                                       (unsigned)lds_slots, balanced);
+            }
+            else if (unroll == 2)
             {
                 if (nt_store == 2)
                     CAVMD_LAUNCH_PERSIST(2, 2)
@@ -1291,6 +1314,27 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->persistent = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "debug_spin_limit"))
+    {
+        if (value < 0)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->debug_spin_limit = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "debug_late_block"))
+    {
+        if (value < -1 || value >= (int)kMaxPersistGrid)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->debug_late_block = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "debug_late_ticks"))
+    {
+        if (value < 0 || value > 100000000) // at most one second
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->debug_late_ticks = value;
+        return CAVMD_OK;
+    }
     if (!strcmp(name, "sync_timeout_seen"))
     {
         // fault-injection hook: raises the flag of the host-visible block as a starved single-launch kernel would -- 1: the
@@ -1357,6 +1401,12 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->persistent;
     else if (!strcmp(name, "sync_timeout_seen"))
         *value = ws->sync_timeout_seen ? 1 : 0;
+    else if (!strcmp(name, "debug_spin_limit"))
+        *value = ws->debug_spin_limit;
+    else if (!strcmp(name, "debug_late_block"))
+        *value = ws->debug_late_block;
+    else if (!strcmp(name, "debug_late_ticks"))
+        *value = ws->debug_late_ticks;
     else if (!strcmp(name, "reduce_unroll"))
         *value = ws->reduce_unroll;
     else if (!strcmp(name, "rho_lane_particle"))

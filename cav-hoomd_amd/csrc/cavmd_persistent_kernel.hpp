@@ -40,10 +40,7 @@ namespace cavmd
 {
 
 constexpr int kGranulesPerRecord = 2 * kNumPartDoubles + kNumPartInts; // 9 doubles as 18 halves + lmin + lcnt
-#ifndef CAVMD_SPIN_LIMIT
-#define CAVMD_SPIN_LIMIT 1000000 // poll rounds of a bounded wait: ~0.4 s; a healthy wait is microseconds
-#endif
-constexpr unsigned kSpinLimit = CAVMD_SPIN_LIMIT;
+constexpr unsigned kSpinLimit = 1000000; // poll rounds of a bounded wait: ~0.2-0.4 s; a healthy wait is microseconds
 constexpr unsigned kRepairRounds = 4096; // the last block of a starved evaluation finds every record in place: no real wait
 
 constexpr int kGroup = 16;           // blocks per first-level group = lanes of a DPP row
@@ -58,6 +55,9 @@ struct SyncState
                                   // kGranulesPerRecord granules {tag << 32 | value} = 160 contiguous bytes
     unsigned* epoch;              // epoch[0]: tag of the next evaluation (never 0); epoch[1]: blocks of the running evaluation
                                   // that gave up waiting (0 outside a starved evaluation)
+    unsigned spin_limit;          // poll rounds of a bounded wait (kSpinLimit; tests shorten it)
+    int late_block;               // fault injection (FAULT instantiation only): this block starts late_ticks of the 100 MHz
+    unsigned late_ticks;          // wall clock late, as if its CU had been held by another grid; -1: none
 };
 // HostResult::sync_error
 constexpr unsigned kSyncFailed = 1u;   // some block gave up and nobody could complete the evaluation: its forces hold NaN
@@ -207,7 +207,7 @@ __device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsign
 
 extern __shared__ __attribute__((aligned(16))) double s_dyn_charge[];
 
-template <int BLOCK, int UNROLL, int NT_STORE>
+template <int BLOCK, int UNROLL, int NT_STORE, bool FAULT = false>
 __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> in, unsigned N, double Lx, double Ly, double Lz,
                                                                   DeviceParams prm, int L_typeid, SyncState st,
                                                                   uint64_t sequence, cavmd_result* __restrict__ res,
@@ -222,14 +222,15 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     const unsigned G = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
 
     CAVMD_PSTAMP(0);
-#ifdef CAVMD_FAULT_LATE_BLOCK // microbench only: this block starts late, as if its CU had been held by another grid
-    if (b == CAVMD_FAULT_LATE_BLOCK)
+    if constexpr (FAULT) // tests only: this block starts late, as if its CU had been held by another grid
     {
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)CAVMD_FAULT_LATE_TICKS)
-            __builtin_amdgcn_s_sleep(64);
+        if ((int)b == st.late_block)
+        {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)st.late_ticks)
+                __builtin_amdgcn_s_sleep(64);
+        }
     }
-#endif
     // this evaluation's tag, and the speculative photon row (the driver appends the photon last)
     const unsigned tag = __hip_atomic_load(st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         {
             // A grid of at most 16 blocks (N up to ~4000) is ONE group: every block gathers the block records itself, its own
             // from registers -- one hop instead of two, and the same fold (the second level would only add zeros).
-            ok = gather_records(block_slab, 0, G, tag, s_words, o, kSpinLimit, (int)b, acc, st.epoch + 1);
+            ok = gather_records(block_slab, 0, G, tag, s_words, o, st.spin_limit, (int)b, acc, st.epoch + 1);
             CAVMD_PSTAMP(7);
         }
         else
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
                 // 1e6 -- 240 extra gathers in flight when the last records land.)
                 const unsigned count = min(G - b, (unsigned)kGroup);
                 Accum o1, t1;
-                ok = gather_records(block_slab, b, count, tag, s_words, o1, kSpinLimit, 0, acc);
+                ok = gather_records(block_slab, b, count, tag, s_words, o1, st.spin_limit, 0, acc);
                 // (a group whose gather timed out publishes nothing: every block then times out on the group totals and
                 // the whole evaluation fails loudly, instead of a wrong total spreading with a valid tag)
                 if (ok)
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             }
             CAVMD_PSTAMP(7);
             ok = gather_records(group_slab + (size_t)(b % kGroupCopies) * kGroup * kGranulesPerRecord, 0,
-                                (G + kGroup - 1) / kGroup, tag, s_words, o, kSpinLimit, -1, acc, st.epoch + 1)
+                                (G + kGroup - 1) / kGroup, tag, s_words, o, st.spin_limit, -1, acc, st.epoch + 1)
                  && ok;
         }
         t.merge(o);

@@ -95,7 +95,7 @@ int main(int argc, char** argv)
     const unsigned epoch_init[2] = {1u, 0u};
     CHECK(hipMemcpy(d_epoch, epoch_init, 8, hipMemcpyHostToDevice));
     Partials part {d_part, d_ipart, max_parts};
-    SyncState sync {d_gran, d_epoch};
+    SyncState sync {d_gran, d_epoch, kSpinLimit, -1, 0u};
     const double L = 215.4;
     const unsigned n = (unsigned)N;
     hipStream_t st = 0;
@@ -144,10 +144,23 @@ int main(int argc, char** argv)
         hipEvent_t a, b2;
         CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b2));
         CHECK(hipEventRecord(a, st));
+#ifdef CAVMD_FAULT_LATE_BLOCK
+        SyncState fsync = sync;
+        fsync.spin_limit = 20000;                    // ~8 ms instead of ~0.3 s
+        fsync.late_block = CAVMD_FAULT_LATE_BLOCK;
+        fsync.late_ticks = 6000000;                  // 60 ms of the 100 MHz clock
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        if (unroll == 2)
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 2, true, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, fsync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+        else
+            hipLaunchKernelGGL((cavity_persistent_kernel<256, 1, true, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, fsync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+#else
         if (unroll == 2)
             hipLaunchKernelGGL((cavity_persistent_kernel<256, 2, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
         else
             hipLaunchKernelGGL((cavity_persistent_kernel<256, 1, true>), dim3(g1), dim3(256), slots * tile * 8, st, in2(0), n, L, L, L, P, 2, sync, 7ull, d_res, d_hres, (v2d*)d_frc[0], (unsigned)slots, false);
+#endif
         CHECK(hipEventRecord(b2, st));
         CHECK(hipEventSynchronize(b2));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b2));

@@ -305,6 +305,10 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *   "sync_timeout_seen"    0..2    read: 1 after a starved evaluation.  Write: fault-injection hook, raises the flag of
  *                                  the host-visible block as a starved kernel would -- 1: failed, 2: completed by its last
  *                                  workgroup (the next call acts on it); write 0: forget it.
+ *   "debug_spin_limit", "debug_late_block", "debug_late_ticks"
+ *                                  test hooks of the single-launch kernel: poll rounds of its bounded waits (0 = default),
+ *                                  and a workgroup (index, -1 = none) that starts late by that many ticks of the 100 MHz
+ *                                  clock, as if its CU had been held by another grid -- a real starved evaluation on demand
  *   "rho_lane_particle"    -1..3   density-field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
  *                                  wavevectors per chunk, -1 auto by n_k
  *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles

@@ -809,6 +809,53 @@ def test_a_sync_timeout_is_reported_once_and_the_workspace_falls_back_to_two_lau
         assert torch.equal(frc, want_f)
 
 
+@pytest.mark.parametrize("n", [2049, 4097, 60_001, 1_000_001])
+def test_a_starved_evaluation_is_completed_by_its_last_block(n):
+    """A REAL starved single-launch evaluation, provoked through the library's test hooks: one block of the grid starts 20 ms
+    late while the others' bounded waits are cut to a few ms, so they all give up and leave, as they would if another grid held
+    that block's CU.  The late block gives up last and completes the evaluation alone.  Expected: no error from any call, the
+    result and EVERY force entry bit for bit those of the two-launch path, and the workspace on two launches afterwards.
+    Late block = the first (a group leader: it would otherwise find all group totals and finish on its own), one in the
+    middle, and the last (the block that normally publishes the result)."""
+    cfg = _random_cfg(n, seed=4100 + n % 97, photon_at=n // 3)
+    dev = "cuda"
+    pos = torch.from_numpy(np.concatenate([cfg["position"], cavitymd.state.type_tag_as_double(cfg["typeid"])[:, None]], axis=1)).to(dev)
+    chg = torch.from_numpy(cfg["charge"]).to(dev)
+    img = torch.from_numpy(cfg["image"]).to(dev)
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    L = cfg["box"]
+    frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    ref_ws = _capi.Workspace(n)
+    ref_ws.set_tunable("persistent", 0)
+    ref_ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+    want = ref_ws.result()
+    torch.cuda.synchronize()
+    want_f = frc.clone()
+    grid = want.n_partials                      # the single-launch grid is the two-launch path's reduction grid
+    for late in sorted({0, min(5, grid - 1), grid - 1}):
+        ws = _capi.Workspace(n)
+        ws.set_tunable("persistent", 1)
+        ws.set_tunable("debug_spin_limit", 5000)
+        ws.set_tunable("debug_late_block", late)
+        ws.set_tunable("debug_late_ticks", 2_000_000)
+        frc.fill_(float("nan"))
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+        got = ws.result()                        # waits for the repaired evaluation; no error
+        assert got.sequence == 1 and got.n_partials == grid
+        for field in ("dipole", "dipole_lo", "total_dipole", "energy", "photon_force", "q"):
+            if hasattr(want, field):
+                assert np.array_equal(np.array(getattr(got, field)[:]), np.array(getattr(want, field)[:])), (late, field)
+        torch.cuda.synchronize()
+        assert torch.equal(frc.view(torch.int64), want_f.view(torch.int64)), f"late block {late} of {grid}"
+        assert ws.get_tunable("persistent") == 0 and ws.get_tunable("sync_timeout_seen") == 1
+        # two launches from here on, no fault hook in that path: same bits again
+        frc.fill_(float("nan"))
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+        assert np.array_equal(np.array(ws.result().dipole[:]), np.array(want.dipole[:]))
+        torch.cuda.synchronize()
+        assert torch.equal(frc.view(torch.int64), want_f.view(torch.int64))
+
+
 def test_environment_switch_for_shared_gpus(monkeypatch):
     """CAVMD_PERSISTENT is read by cavmd_create: 0 = two launches (GPUs shared by more processes than fit), 1 = always one."""
     for env, want in (("0", 0), ("1", 1), ("bogus", -1)):
