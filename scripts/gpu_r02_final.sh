@@ -11,6 +11,7 @@ timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-bas
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err && \
 (cd cav-hoomd_amd/csrc && for n in "100001 64" "300001 22" "1000001 7" "4000001 2"; do set -- $n; timeout -k 10 200 ./microbench_persistent $1 $2 9 20 > $R/$O/mbp_final_$1.txt 2>&1 || exit 1; done) && \
 timeout -k 10 60 scripts/dev/pingpong 2000 > $O/pingpong.txt 2>&1 && \
+(cd cav-hoomd_amd/csrc && for n in 1000001 100001 3001 2049; do timeout -k 10 60 ./microbench_persistent_late $n 1 1 1 | tail -1 || exit 1; done > $R/$O/fault_late.txt 2>&1 && for n in 1000001 3001; do timeout -k 10 60 ./microbench_persistent_fault $n 1 1 1 | tail -1 || exit 1; done > $R/$O/fault_silent.txt 2>&1) && \
 cd /tmp && export TMPDIR=/tmp && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_1e6 -- python3 $R/bench.py --no-extras --no-cpu-baseline > $R/$O/prof_1e6.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_write_1e6 -- python3 $R/bench.py --steps 30 --warmup 5 --no-extras --no-cpu-baseline > $R/$O/pmc_write_1e6.log 2>&1 && \
