@@ -35,6 +35,8 @@
  *     the reference).  A workspace that has been captured reads its results (cavmd_result_read,
  *     cavmd_energies) behind a hipDeviceSynchronize instead of the host-visible flag: a replayed kernel
  *     carries the sequence number of its capture, so the flag cannot tell replays apart.
+ *     A graph whose replay ended in CAVMD_ERR_SYNC_TIMEOUT must be captured again before it is replayed (the
+ *     library's own recovery -- two launches, wiped hand-off slabs -- does not reach into a captured graph).
  *   - Scalar = double (HOOMD's default HOOMD_LONGREAL_SIZE=64 build).
  *
  * Semantic contract (what "the same result as the reference" means here; file:line = reference)
