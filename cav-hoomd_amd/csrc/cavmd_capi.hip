@@ -45,6 +45,7 @@ constexpr size_t kChargeTemporalMaxN = 25000000; // charges stay temporal while 
                                                  // 6e6 and 1e7, -5 % at 2e7, tie at 5e7 (profiles/r02/ab_two_launch_knobs.txt)
 constexpr int kPersistBlock = 256;
 constexpr size_t kPersistMaxLds = 156 * 1024; // dynamic LDS of the single-launch kernel (charges of a block's tiles); 160 KiB per CU
+constexpr uint64_t kSuspendFirst = 1ull << 16, kSuspendMax = 1ull << 31, kSuspendForever = ~0ull;
 constexpr size_t kPersistSharedLds = 76 * 1024; // default ceiling: two such blocks (+ 1.7 KiB static each) fit on one CU, so two concurrent grids stay resident
 
 static_assert(sizeof(cavmd_double4) == 32, "Scalar4 layout");
@@ -92,6 +93,10 @@ struct cavmd_workspace
     int debug_spin_limit = 0;     // tests: poll rounds of the single-launch kernel's bounded waits (0 = kSpinLimit)
     int debug_late_block = -1;    // tests: this block of the single-launch grid starts debug_late_ticks late (-1 = none)
     int debug_late_ticks = 0;     //        (100 MHz wall clock)
+    // after a starved evaluation the single launch is suspended: until sequence reaches suspend_until, then one probe; every
+    // further starvation multiplies the pause by 8 (2^16 evaluations at first, 2^31 at most); a FAILED one suspends for good
+    uint64_t suspend_until = 0;
+    uint64_t suspend_backoff = kSuspendFirst;
     bool sync_state_dirty = false;  // a starved evaluation may have left records or counts behind: wipe before the next single launch
     bool sync_timeout_seen = false; // an inter-workgroup wait of the single-launch kernel gave up once: two launches from then on
     bool captured = false; // some evaluation was enqueued into a stream capture: the host-side flag protocol is off
@@ -486,9 +491,9 @@ namespace
 {
 // A single-launch evaluation whose blocks were not resident together (other grids held the CUs) either got completed by its
 // last block alone (kSyncRepaired: results valid, it just took a second) or failed (kSyncFailed: NaN forces) -- see the
-// bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- turns the
-// single-launch path off for this workspace for good: what starved the grid is a property of the deployment, not of one
-// step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
+// bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- suspends the
+// single-launch path for this workspace: what starved the grid is a property of how the GPU is shared at the moment, not of
+// one step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
 unsigned consume_sync_timeout(cavmd_workspace* ws)
 {
     if (!ws->h_result || !__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
@@ -504,10 +509,19 @@ unsigned consume_sync_timeout(cavmd_workspace* ws)
     __atomic_store_n(&ws->h_result->sync_error, 0u, __ATOMIC_RELEASE);
     ws->sync_timeout_seen = true;
     ws->sync_state_dirty = true;
-    ws->persistent = 0;
-    if (verdict != kSyncRepaired)
-        ws->computed = false; // the result block still holds the evaluation BEFORE the failed one
-    return verdict == kSyncRepaired ? kSyncRepaired : kSyncFailed;
+    if (verdict == kSyncRepaired)
+    {
+        // two launches for a while, then one probe: whoever held the CUs may have gone.  A probe that starves again costs one
+        // slow (valid) evaluation and an 8 times longer pause.
+        if (ws->sequence - ws->suspend_until > ws->suspend_backoff)
+            ws->suspend_backoff = kSuspendFirst; // the single launch had been healthy for longer than the last pause: start over
+        ws->suspend_until = ws->sequence + ws->suspend_backoff;
+        ws->suspend_backoff = ws->suspend_backoff * 8 < kSuspendMax ? ws->suspend_backoff * 8 : kSuspendMax;
+        return kSyncRepaired;
+    }
+    ws->suspend_until = kSuspendForever; // not understood: stay off until the caller switches it on again
+    ws->computed = false;                // the result block still holds the evaluation BEFORE the failed one
+    return kSyncFailed;
 }
 } // namespace
 
@@ -605,8 +619,9 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         // Nor by default beyond half a CU's LDS per block (N >~ 2.4e6): two such grids from different streams or processes
         // could then not be resident side by side, and two half-resident grids would wait for each other until their
         // bounded spins give up (a loud CAVMD_ERR_SYNC_TIMEOUT, but a failure).  persistent = 1 lifts both limits.
-        if (resident && (ws->persistent > 0
-                         || (ws->persistent < 0 && slots <= cap_slots && lds <= kPersistSharedLds && persistent_auto(N))))
+        if (resident && ws->sequence >= ws->suspend_until
+            && (ws->persistent > 0
+                || (ws->persistent < 0 && slots <= cap_slots && lds <= kPersistSharedLds && persistent_auto(N))))
         {
             if (ws->sync_state_dirty)
             {
@@ -1312,6 +1327,15 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         if (value < -1 || value > 1)
             return CAVMD_ERR_INVALID_VALUE;
         ws->persistent = value;
+        ws->suspend_until = 0; // the caller's word ends a suspension (the hand-off slabs are wiped before the next single launch)
+        ws->suspend_backoff = kSuspendFirst;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "debug_suspend_first"))
+    {
+        if (value < 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->suspend_backoff = (uint64_t)value;
         return CAVMD_OK;
     }
     if (!strcmp(name, "debug_spin_limit"))
@@ -1401,6 +1425,8 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->persistent;
     else if (!strcmp(name, "sync_timeout_seen"))
         *value = ws->sync_timeout_seen ? 1 : 0;
+    else if (!strcmp(name, "persistent_suspended"))
+        *value = ws->suspend_until == kSuspendForever ? 2 : (ws->sequence < ws->suspend_until ? 1 : 0);
     else if (!strcmp(name, "debug_spin_limit"))
         *value = ws->debug_spin_limit;
     else if (!strcmp(name, "debug_late_block"))

@@ -298,19 +298,24 @@ CAVMD_API int cavmd_profile_samples(cavmd_workspace* ws, double* out, size_t cap
  *                                  evaluation is late but valid and is not reported as an error.  If it cannot be
  *                                  completed (not observed outside fault injection) the forces stay NaN and the result
  *                                  read or the NEXT cavmd_compute_* call, whichever comes first, returns
- *                                  CAVMD_ERR_SYNC_TIMEOUT (that call enqueues nothing).  In both cases the workspace
- *                                  stays on two launches afterwards ("persistent" reads 0, "sync_timeout_seen" reads 1):
- *                                  a grid that was starved once will be again while the GPU is shared the same way.  A
- *                                  GPU known to be shared by three or more processes that each evaluate N > 1024 can
- *                                  skip the one slow step with the environment variable CAVMD_PERSISTENT=0, read by
- *                                  cavmd_create (=1 forces the single launch).
+ *                                  CAVMD_ERR_SYNC_TIMEOUT (that call enqueues nothing).  After a starved evaluation the
+ *                                  workspace SUSPENDS the single launch ("sync_timeout_seen" reads 1): two launches for
+ *                                  2^16 evaluations, then one probe -- whoever held the CUs may have gone; a probe that
+ *                                  starves again (late but valid, as before) makes the pause 8 times longer, up to 2^31;
+ *                                  a pause starts over at 2^16 once the single launch has run healthy for longer than
+ *                                  the last pause.  After a FAILED evaluation it stays suspended until the caller
+ *                                  writes this tunable again.  A GPU known to be shared by three or more processes that
+ *                                  each evaluate N > 1024 can skip the slow steps with the environment variable
+ *                                  CAVMD_PERSISTENT=0, read by cavmd_create (=1 forces the single launch).
+ *   "persistent_suspended" (read only)  0: no; 1: paused after a starved evaluation; 2: off after a failed one
  *   "sync_timeout_seen"    0..2    read: 1 after a starved evaluation.  Write: fault-injection hook, raises the flag of
  *                                  the host-visible block as a starved kernel would -- 1: failed, 2: completed by its last
  *                                  workgroup (the next call acts on it); write 0: forget it.
- *   "debug_spin_limit", "debug_late_block", "debug_late_ticks"
+ *   "debug_spin_limit", "debug_late_block", "debug_late_ticks", "debug_suspend_first"
  *                                  test hooks of the single-launch kernel: poll rounds of its bounded waits (0 = default),
- *                                  and a workgroup (index, -1 = none) that starts late by that many ticks of the 100 MHz
- *                                  clock, as if its CU had been held by another grid -- a real starved evaluation on demand
+ *                                  a workgroup (index, -1 = none) that starts late by that many ticks of the 100 MHz
+ *                                  clock, as if its CU had been held by another grid -- a real starved evaluation on
+ *                                  demand -- and the length of the next pause in evaluations
  *   "rho_lane_particle"    -1..3   density-field mapping: 0 lane = wavevector, 1 / 2 / 3 lane = particle with 25 / 10 / 5
  *                                  wavevectors per chunk, -1 auto by n_k
  *   "persistent_lds_kb"    0..156  LDS budget per block of the single-launch kernel in KiB (0 = default); the charges of tiles

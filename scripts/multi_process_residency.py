@@ -9,8 +9,8 @@ evaluation, whichever it is, gets checked.
 
 The parent never touches the GPU; it starts <processes> children (fresh interpreters), which build their own system,
 wait for a common start time and then evaluate back to back, reading the result every 25 evaluations (that is where a
-time-out surfaces as CAVMD_ERR_SYNC_TIMEOUT).  Each child reports its rate, the time-outs it saw, and whether its
-workspace fell back to two launches ("persistent" tunable 0 afterwards).  Keep <processes> <= 6 (gpurun's process guard).
+failed evaluation would surface as CAVMD_ERR_SYNC_TIMEOUT).  Each child reports its rate, the errors it saw, whether it met
+a starved evaluation ("sync_timeout_seen") and whether its single launch is suspended at the end.  Keep <processes> <= 6 (gpurun's process guard).
 """
 import json
 import os
@@ -70,7 +70,7 @@ def child(n_mol, evals, persistent, start_at, verify):
     dt = time.perf_counter() - t0
     print(json.dumps({"pid": os.getpid(), "N": n, "evals_per_s": done / dt, "timeouts": timeouts, "wrong_results": wrong,
                       "evaluations_with_wrong_forces": int(force_mismatches.item()) if verify else None,
-                      "persistent_after": ws.get_tunable("persistent"),
+                      "single_launch_suspended": ws.get_tunable("persistent_suspended"),
                       "sync_timeout_seen": ws.get_tunable("sync_timeout_seen")}), flush=True)
 
 

@@ -802,7 +802,7 @@ def test_a_sync_timeout_is_reported_once_and_the_workspace_falls_back_to_two_lau
         with pytest.raises(_capi.CavmdError) as ei:
             ws.result()                                  # the stale result is not handed out as current
         assert ei.value.status == _capi.CAVMD_ERR_NOT_COMPUTED
-        assert ws.get_tunable("persistent") == 0 and ws.get_tunable("sync_timeout_seen") == 1
+        assert ws.get_tunable("persistent_suspended") == 2 and ws.get_tunable("sync_timeout_seen") == 1   # for good
         ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())   # two launches now
         assert np.array_equal(np.array(ws.result().dipole[:]), want_d)
         torch.cuda.synchronize()
@@ -814,7 +814,7 @@ def test_a_starved_evaluation_is_completed_by_its_last_block(n):
     """A REAL starved single-launch evaluation, provoked through the library's test hooks: one block of the grid starts 20 ms
     late while the others' bounded waits are cut to a few ms, so they all give up and leave, as they would if another grid held
     that block's CU.  The late block gives up last and completes the evaluation alone.  Expected: no error from any call, the
-    result and EVERY force entry bit for bit those of the two-launch path, and the workspace on two launches afterwards.
+    result and EVERY force entry bit for bit those of the two-launch path, and the single launch suspended afterwards.
     Late block = the first (a group leader: it would otherwise find all group totals and finish on its own), one in the
     middle, and the last (the block that normally publishes the result)."""
     cfg = _random_cfg(n, seed=4100 + n % 97, photon_at=n // 3)
@@ -847,13 +847,65 @@ def test_a_starved_evaluation_is_completed_by_its_last_block(n):
                 assert np.array_equal(np.array(getattr(got, field)[:]), np.array(getattr(want, field)[:])), (late, field)
         torch.cuda.synchronize()
         assert torch.equal(frc.view(torch.int64), want_f.view(torch.int64)), f"late block {late} of {grid}"
-        assert ws.get_tunable("persistent") == 0 and ws.get_tunable("sync_timeout_seen") == 1
-        # two launches from here on, no fault hook in that path: same bits again
+        assert ws.get_tunable("persistent_suspended") == 1 and ws.get_tunable("sync_timeout_seen") == 1
+        # two launches for now, no fault hook in that path: same bits again
         frc.fill_(float("nan"))
         ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
         assert np.array_equal(np.array(ws.result().dipole[:]), np.array(want.dipole[:]))
         torch.cuda.synchronize()
         assert torch.equal(frc.view(torch.int64), want_f.view(torch.int64))
+
+
+def test_a_suspended_single_launch_is_probed_again_with_back_off():
+    """After a starved (repaired) evaluation the workspace evaluates with two launches for a pause, then tries the single
+    launch again; a probe that starves again is repaired again and the pause grows eightfold.  Which path an evaluation took
+    is read from the per-kernel timers (the force-map slot is used by the two-launch path only)."""
+    n = 60_001
+    cfg = _random_cfg(n, seed=515, photon_at=n - 1)
+    dev = "cuda"
+    pos = torch.from_numpy(np.concatenate([cfg["position"], cavitymd.state.type_tag_as_double(cfg["typeid"])[:, None]], axis=1)).to(dev)
+    chg = torch.from_numpy(cfg["charge"]).to(dev)
+    img = torch.from_numpy(cfg["image"]).to(dev)
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    L = cfg["box"]
+    frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    ws = _capi.Workspace(n)
+    ws.set_tunable("persistent", 1)
+    ws.profile_enable(True)
+
+    def evaluate():
+        """-> (launches used, dipole)"""
+        frc.fill_(float("nan"))
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
+        d = np.array(ws.result().dipole[:])
+        ms, count = ws.profile_read()
+        assert count == 1
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(frc).any())
+        return (2 if ms[2] > 0 else 1), d
+
+    launches, want = evaluate()
+    assert launches == 1 and ws.get_tunable("persistent_suspended") == 0
+    # evaluation 2 starves (block 3 starts late) and is repaired; first pause cut from 2^16 to 4 evaluations
+    for k, v in (("debug_spin_limit", 5000), ("debug_late_block", 3), ("debug_late_ticks", 2_000_000), ("debug_suspend_first", 4)):
+        ws.set_tunable(k, v)
+    launches, d = evaluate()
+    assert launches == 1 and np.array_equal(d, want) and ws.get_tunable("persistent_suspended") == 1
+    ws.set_tunable("debug_late_block", -1)            # whoever held the CU has gone
+    path = []
+    for _ in range(6):
+        launches, d = evaluate()
+        assert np.array_equal(d, want)
+        path.append(launches)
+    assert path == [2, 2, 2, 2, 1, 1], path           # four evaluations on two launches, then the probe, which stays
+    assert ws.get_tunable("persistent_suspended") == 0
+    # the next starvation comes soon after the probe: the pause is eight times as long
+    ws.set_tunable("debug_late_block", 3)
+    launches, d = evaluate()
+    assert launches == 1 and np.array_equal(d, want) and ws.get_tunable("persistent_suspended") == 1
+    ws.set_tunable("debug_late_block", -1)
+    path = [evaluate()[0] for _ in range(34)]
+    assert path == [2] * 32 + [1, 1], path
 
 
 def test_environment_switch_for_shared_gpus(monkeypatch):
