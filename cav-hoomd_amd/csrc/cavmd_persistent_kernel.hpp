@@ -1,4 +1,4 @@
-// cavmd_persistent_kernel.hpp -- the whole cavity-force evaluation in ONE launch (N > 2048).
+// cavmd_persistent_kernel.hpp -- the whole cavity-force evaluation in ONE launch (1024 < N <~ 2.4e6 by default).
 //
 //   phase 1   every block streams its tiles (pos 32 + charge 8 + image 12 B per particle) exactly as
 //             dipole_partials_kernel does -- same tile assignment, same double-double accumulation, same block tree,
@@ -23,8 +23,13 @@
 // N = 1e6 whichever way the waiting was organised (profiles/r02/microbench_persistent_flat_*.txt); here a waiting block
 // polls 20 lines, from ONE wave.  The tag is the epoch word of the workspace, read from DEVICE memory at kernel start and
 // advanced by the publishing block once it holds the total (every block has published by then, so every block has read it): a
-// captured launch replays correctly, nothing needs zeroing between launches.  Every spin is bounded: on a time-out the
-// block raises the sync_error word of the host-visible result block and fills its share of the force array with NaN.
+// captured launch replays correctly, nothing needs zeroing between launches.  Grids of at most 16 blocks skip the first
+// level (every block gathers the block records itself).
+//
+// Starvation: when other grids hold CUs, part of this grid cannot start while the rest waits for it.  Every spin is
+// bounded; a block that gives up poisons its tiles with NaN, is counted and LEAVES, which lets the missing blocks start; they
+// give up in turn (the count rides along with their polls), and the last one, which knows from the count that every record
+// is in place, folds them in the same order and writes every tile itself -- late, but the same bits (bail path below).
 #pragma once
 
 #include "cavmd_force_kernels.hpp"
