@@ -20,7 +20,7 @@
 // no dependence on dispatch order, timing or XCD placement are needed -- only that all blocks of the grid are resident
 // together (grid <= CUs, one block per CU fits by construction).  Why two levels: a flat all-gather (every block reads
 // every record) makes up to 1024 waves spin on the same 320 lines of the memory side -- measured 4.6 us per hand-off at
-// N = 1e6 whichever way the waiting was organised (profiles/r02/microbench_persistent_flat_*.txt); here a waiting block
+// N = 1e6 whichever way the waiting was organised (profiles/r02/microbench_persistent_v1_flat_*.txt); here a waiting block
 // polls 20 lines, from ONE wave.  The tag is the epoch word of the workspace, read from DEVICE memory at kernel start and
 // advanced by the publishing block once it holds the total (every block has published by then, so every block has read it): a
 // captured launch replays correctly, nothing needs zeroing between launches.  Grids of at most 16 blocks skip the first
