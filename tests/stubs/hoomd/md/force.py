@@ -60,3 +60,12 @@ class Custom(Force):
         if not self._attached or self._cpp_obj is None:
             raise RuntimeError("Cannot access arrays before attaching")   # what the real class does for an unattached force
         yield _ForceArrays(self._simulation.state._force4_for(self))
+
+    @property
+    @contextlib.contextmanager
+    def cpu_local_force_arrays(self):
+        """Host flavour of the same container (numpy Scalar4 buffer); used by tests/golden/make_golden.py when it lets the
+        reference's own Python force write into it."""
+        if self._cpp_obj is None:
+            raise RuntimeError("Cannot access arrays before attaching")
+        yield _ForceArrays(self._simulation.state._force4_for(self))

@@ -50,3 +50,75 @@ def test_force_mass_sum_closed_form():
     m = np.array([5.0, 4.0, 0.5])
     assert obs.force_mass_sum(f, m) == 1.0 + 0.5 + 6.0 == obs.force_mass_sum_exact(f, m)
     assert prod.adaptive_timestep(0.3, 7.5) == (0.3 / 7.5) ** 0.5 and prod.adaptive_timestep(0.3, 0.0) is None
+
+
+# ---- against numbers the reference's own analysis.py / simulation.py computed (tests/golden/reference_python_golden.npz) ---
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with np.load(os.path.join(golden_dir, "reference_python_golden.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_fibonacci_sphere_against_the_executed_reference(gold):
+    """Same construction, but math.cos/sin here vs numpy's in the reference: <= 1 ulp per coordinate; the product's
+    vectorised version (the wavevector sets users exchange with the reference) likewise."""
+    for n in (2, 10, 50, 100):
+        want = gold[f"fibonacci/{n}"]
+        assert np.abs(obs.fibonacci_sphere(n) - want).max() <= 2.3e-16
+        assert np.abs(prod.generate_fibonacci_sphere(n) - want).max() <= 2.3e-16
+
+
+def test_density_field_and_F_kt_against_the_executed_reference(gold):
+    frames = gold["trajectory/frames"]
+    n = frames.shape[1]
+    for key in ("density/k1.0_n50", "density/k0.35_n17", "density/k2.5_n64"):
+        k = gold[key + "/wavevectors"]
+        nk = k.shape[0]
+        kmag = float(key.split("/k")[1].split("_")[0])
+        if nk == 50:                                                # the tracker's wavevectors = kmag * the sphere (:304-306)
+            assert np.array_equal(k, gold["fibonacci/50"] * kmag)
+        rho = np.array([obs.density_field(f, k) for f in frames])
+        assert np.array_equal(rho, gold[key + "/rho_k"])            # the same numpy expressions: the same bits
+        exact = np.array([obs.density_field_exact(f, k) for f in frames])
+        assert np.abs(exact - gold[key + "/rho_k"]).max() <= 1e-13 * n
+        # F(k,t) = mean_k Re(rho_k(0) conj(rho_k(t)))   (analysis.py:359-364)
+        want = gold[key + "/F_kt"]
+        got = [np.mean(np.real(rho[0] * np.conj(rho[t]))) for t in range(1, len(frames))]
+        assert np.isnan(want[0]) and np.array_equal(got, want[1:])
+
+
+def test_total_dipole_and_C_t_against_the_executed_reference(gold):
+    frames = gold["trajectory/frames"]
+    image, charge, box = (gold["force/n501_stand_in/" + k] for k in ("image", "charge", "box"))
+    d = np.array([obs.total_dipole_moment(f, image, charge, box) for f in frames])
+    assert np.array_equal(d, gold["dipole_acf/dipole_t"])
+    assert np.array_equal([np.dot(d[0], x) for x in d], gold["dipole_acf/C_t"])
+
+
+def test_cavity_mode_against_the_executed_reference(gold):
+    for i in range(3):
+        g = {k: gold[f"cavity_mode/{i}/{k}"] for k in ("typeid", "mass", "velocity", "harmonic_energy", "properties")}
+        got = obs.cavity_mode(g["velocity"], g["mass"], g["typeid"], float(g["harmonic_energy"]), L_typeid=2)
+        assert np.array_equal(got, g["properties"])
+    assert not gold["cavity_mode/no_photon/properties"].any()
+
+
+def test_adaptive_timestep_rule_against_the_executed_reference(gold):
+    """AdaptiveTimestepUpdater.act: tol(t) = target - (target - initial) exp(-t/tau) with initial = 0.01 target, tau = 50 ps;
+    S = sum |f_a + f_b| / m; dt = sqrt(tol / S); thermostat taus converted with ps_to_atomic_units."""
+    from cavitymd.utils import PhysicalConstants as PC
+    for i in range(3):
+        g = {k: gold[f"adaptive_dt/{i}/{k}"] for k in ("mass", "force_a", "force_b", "elapsed_ps", "error_tolerance", "dt", "tau")}
+        tol = 1e-3 - (1e-3 - 1e-3 * 0.01) * np.exp(-float(g["elapsed_ps"]) / 50.0)
+        assert tol == float(g["error_tolerance"])
+        S = obs.force_mass_sum(g["force_a"] + g["force_b"], g["mass"])
+        assert np.sqrt(tol / S) == float(g["dt"])
+        assert prod.adaptive_timestep(tol, S) == pytest.approx(float(g["dt"]), rel=4e-16)
+        assert abs(obs.force_mass_sum_exact(g["force_a"] + g["force_b"], g["mass"]) - S) <= 1e-13 * S
+        assert np.array_equal(g["tau"], [PC.ps_to_atomic_units(5.0), PC.ps_to_atomic_units(0.5)])
+    assert float(gold["adaptive_dt/zero_force/dt"]) == 0.5      # S == 0: dt untouched (simulation.py:88)
