@@ -38,10 +38,10 @@ for _p in (ROOT, os.path.join(ROOT, "cav-hoomd_amd")):
         sys.path.insert(0, _p)
 
 
-def launch_ranks(n_ranks, argv):
+def launch_ranks(n_ranks, argv, script=None):
     """`python bench.py --gpus N` outside torch.distributed.run: start N fresh child processes (one per LOCAL_RANK, the
     environment torch.distributed.run would give them), relay their output, print rank 0's JSON line LAST and return
-    the worst exit code.  Called before torch / the HIP library are imported: this parent never touches a GPU and
+    the worst exit code.  (`script`: the program the ranks run, this file unless a test substitutes a probe.)  Called before torch / the HIP library are imported: this parent never touches a GPU and
     nothing is exec'ed after GPU initialisation (the reference runs its replicas as separate processes too:
     one SLURM array task per replica, submit.sh:3)."""
     with socket.socket() as sk:
@@ -54,7 +54,7 @@ def launch_ranks(n_ranks, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=out0_file if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     # Wait for all ranks; if one fails, the others would sit in a collective until its time-out: end them (exactly the
     # children started above) after a short grace period instead.
@@ -167,9 +167,10 @@ def timed(ring, steps, warmup, ctx=None):
     t0 = time.perf_counter()
     run_steps(ring, steps, first=warmup)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0          # this rank's K steps on its own clock
     if ctx is not None:
         replicas.barrier(ctx)
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, own    # (the contract's bracket: barrier + synchronize on both sides, this rank's own)
 
 
 def kernel_times(ring, steps, warmup):
@@ -289,7 +290,7 @@ def cpu_baseline(cfg, budget_s):
 
 def side_measurement(cfg, device, frames, steps, warmup):
     ring = build_ring(cfg, frames, device)
-    t = timed(ring, steps, warmup)
+    t, _ = timed(ring, steps, warmup)
     kt, _, _ = kernel_times(ring, steps, warmup)
     n = ring[0].n
     launches = 1 if kt[2] == 0 else (2 if kt[1] == 0 else 3)
@@ -425,9 +426,11 @@ def main():
     n = ring[0].n
     torch.cuda.synchronize()
 
-    elapsed = timed(ring, spec["steps"], spec["warmup"], ctx)
+    elapsed, own = timed(ring, spec["steps"], spec["warmup"], ctx)
     elapsed = replicas.max_over_ranks(ctx, elapsed)
     value = ctx.world_size * spec["steps"] / elapsed
+    # every rank's own rate (its K steps over its own clock between the two barriers): an imbalanced node shows here
+    per_rank = {"min": replicas.min_over_ranks(ctx, spec["steps"] / own), "max": replicas.max_over_ranks(ctx, spec["steps"] / own)}
 
     kt, launches, samples = kernel_times(ring, spec["steps"], spec["warmup"])
     roof = roofline_block(n, kt)
@@ -449,7 +452,10 @@ def main():
                    "N_particles": n, "frames": spec["frames"], "primed_frames": spec["frames"],
                    "replicas": ctx.world_size,
                    "algorithmic_bytes_per_eval": BYTES_EVAL * n, "layout": "HOOMD AoS (Scalar4 pos/force, int3 image)",
-                   "collectives_on_data_path": 0},
+                   "collectives_on_data_path": 0,
+                   # the job's control collectives (start-up broadcast, barriers, MAX/MIN of the timing): "nccl" = RCCL
+                   "dist_backend": ctx.backend, "dist_collective_device": str(ctx.coll_device) if ctx.backend else None},
+        "per_rank_evals_per_s": per_rank,
         "achieved_GBps_wall": BYTES_EVAL * n * value / 1e9,
         "roofline": roof,
     }

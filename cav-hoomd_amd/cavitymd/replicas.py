@@ -65,7 +65,10 @@ class ReplicaContext:
 
     @property
     def is_distributed(self) -> bool:
-        return self.world_size > 1
+        """True when this process has joined a torch.distributed job -- also a job of ONE rank (torch.distributed.run
+        --nproc-per-node 1): the collectives then really run (over RCCL on a GPU box), which is how the one-GPU test box
+        exercises the N > 1 code path's backend calls."""
+        return self.backend is not None
 
 
 def init_from_env(prefer_gpu: bool = True) -> ReplicaContext:
@@ -79,7 +82,10 @@ def init_from_env(prefer_gpu: bool = True) -> ReplicaContext:
         torch.cuda.set_device(device)
     backend = None
     coll_device = torch.device("cpu")
-    if world > 1:
+    # a launcher's environment (WORLD_SIZE and MASTER_ADDR both set) means "join the job", whatever its size; a plain
+    # `python bench.py` has neither and stays a single process without a process group
+    launched = "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched:
         # nccl == RCCL over xGMI on the GPU box.  CAVMD_DIST_BACKEND=gloo keeps the compute on the GPU but runs the
         # handful of control collectives over gloo: used to rehearse an N-rank job on a box with fewer GPUs than ranks
         # (RCCL refuses two ranks on one device).
@@ -134,6 +140,14 @@ def max_over_ranks(ctx: ReplicaContext, value: float) -> float:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.coll_device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def min_over_ranks(ctx: ReplicaContext, value: float) -> float:
+    if not ctx.is_distributed:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=ctx.coll_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return float(t.item())
 
 

@@ -52,6 +52,9 @@ def test_two_rank_rehearsal():
     # whole-job aggregate: two replicas' evaluations over the slowest rank's time
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    pr = d["per_rank_evals_per_s"]       # each rank's own K steps on its own clock: min <= max, both >= the whole-job per-rank rate
+    assert 0 < pr["min"] <= pr["max"] and pr["min"] >= d["value"] / 2 * (1 - 1e-9)
+    assert d["config"]["dist_backend"] == "gloo"
 
 
 def test_plain_gpus2_form_self_launches():

@@ -139,3 +139,69 @@ def test_bench_self_launch_plumbing_without_a_gpu():
         assert out.returncode != 0
         assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
         assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launch_ranks_hands_out_eight_ranks_and_relays_rank0_json_last(tmp_path, capfd):
+    """The driver's N = 8 form, `python bench.py --gpus 8`, without a GPU: the parent starts eight processes with
+    RANK = LOCAL_RANK = 0..7, WORLD_SIZE = LOCAL_WORLD_SIZE = 8, ONE rendezvous address 127.0.0.1:<port> for all, the dmabuf
+    IPC switch set; whatever the ranks print, rank 0's JSON line is the last thing on stdout; the exit code is the worst."""
+    import json
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import json, os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')\n"
+        "json.dump({k: os.environ.get(k) for k in keys} | {'argv': sys.argv[1:]}, open(os.path.join(sys.argv[1], f'env{r}.json'), 'w'))\n"
+        "if r == 0:\n"
+        "    print('NCCL version banner'); print(json.dumps({'metric': 'm', 'value': 1.0})); print('trailing chatter')\n"
+        "else:\n"
+        "    time.sleep(0.05 * r); print(f'rank {r} says hello')\n"
+        "sys.exit(int(sys.argv[2]) if r == 5 else 0)\n")
+    sys.path.insert(0, root)
+    import bench
+    rc = bench.launch_ranks(8, [str(tmp_path), "0"], script=str(probe))
+    out, err = capfd.readouterr()
+    assert rc == 0
+    assert out.strip().splitlines() == [json.dumps({"metric": "m", "value": 1.0})]       # and nothing else on stdout
+    assert "NCCL version banner" in err and "trailing chatter" in err and "rank 7 says hello" in err
+    envs = [json.load(open(tmp_path / f"env{r}.json")) for r in range(8)]
+    assert [e["RANK"] for e in envs] == [e["LOCAL_RANK"] for e in envs] == [str(r) for r in range(8)]
+    assert {e["WORLD_SIZE"] for e in envs} == {e["LOCAL_WORLD_SIZE"] for e in envs} == {"8"}
+    assert {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"} and len({e["MASTER_PORT"] for e in envs}) == 1
+    assert {e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs} == {"0"}
+    assert all(e["argv"] == [str(tmp_path), "0"] for e in envs)
+    # one failing rank: its exit code comes back (the others have finished by themselves here)
+    assert bench.launch_ranks(8, [str(tmp_path), "3"], script=str(probe)) == 3
+    capfd.readouterr()
+
+
+def test_a_launched_job_of_one_rank_joins_a_process_group(tmp_path):
+    """WORLD_SIZE=1 from a launcher still means `join`: the collectives run (gloo here, RCCL on the GPU box) instead of being
+    skipped, so a one-GPU box exercises the same calls as the 8-GPU job.  A plain process (no launcher variables) joins nothing."""
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    code = ("import os, sys\n"
+            f"sys.path[:0] = [{root!r}, os.path.join({root!r}, 'cav-hoomd_amd')]\n"
+            "import torch.distributed as dist\n"
+            "from cavitymd import replicas\n"
+            "ctx = replicas.init_from_env(prefer_gpu=False)\n"
+            "print('JOINED', ctx.is_distributed, ctx.backend, dist.is_initialized())\n"
+            "spec = replicas.broadcast_spec(ctx, {'omegac': 0.5, 'n_molecular': 12, 'steps': 3})\n"
+            "replicas.barrier(ctx)\n"
+            "print('VALUES', spec['n_molecular'], replicas.max_over_ranks(ctx, 1.5), replicas.min_over_ranks(ctx, 2.5), replicas.sum_over_ranks(ctx, 3.5))\n"
+            "replicas.shutdown(ctx)\n")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=base)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "JOINED False None False" in out.stdout and "VALUES 12 1.5 2.5 3.5" in out.stdout
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(base, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "JOINED True gloo True" in out.stdout and "VALUES 12 1.5 2.5 3.5" in out.stdout
