@@ -181,11 +181,28 @@ struct BlockRange
     size_t first, step, tail_base;
     unsigned nfull, tail_count;
 };
+//   hybrid    (partition 2) the full rounds strided -- every block the same floor(full_tiles / G) tiles -- and what is left
+//             (fewer than G tiles' worth of particles) cut into G contiguous shares of whole 64-particle units, one ragged
+//             tile per block: equal work to within 64 particles AND the strided sweep for all but the last round.
 template <unsigned TILE>
-__device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsigned b, bool balanced)
+__device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsigned b, int balanced)
 {
     BlockRange r;
-    if (balanced)
+    if (balanced == 2)
+    {
+        const unsigned rounds = (N / TILE) / G;
+        const size_t done = (size_t)rounds * G * TILE;
+        const unsigned long long U = ((unsigned long long)(N - done) + kWave - 1) / kWave;
+        const size_t s = done + (size_t)(U * b / G) * kWave;
+        size_t e = done + (size_t)(U * (b + 1) / G) * kWave;
+        e = e < N ? e : N;
+        r.first = (size_t)b * TILE;
+        r.step = (size_t)G * TILE;
+        r.nfull = rounds;
+        r.tail_base = s;
+        r.tail_count = (unsigned)(e > s ? e - s : 0);
+    }
+    else if (balanced)
     {
         const unsigned long long U = ((unsigned long long)N + kWave - 1) / kWave;
         const size_t s = (size_t)(U * b / G) * kWave;
@@ -212,12 +229,16 @@ __device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsign
 
 extern __shared__ __attribute__((aligned(16))) double s_dyn_charge[];
 
-template <int BLOCK, int UNROLL, int NT_STORE, bool FAULT = false>
+// EARLYZ: half of every force entry -- the odd 16-byte chunk (F_z, w) = (0, 0) of every particle that is not the photon --
+// does not depend on the total.  With EARLYZ waves 1..3 of a block write those chunks of the block's own tiles WHILE wave 0
+// runs the hand-off, i.e. while the memory system would otherwise sit idle (~3-4 us per evaluation at N = 1e6), and phase 2
+// writes the even chunks only (plus the photon's odd chunk, over the zero).
+template <int BLOCK, int UNROLL, int NT_STORE, bool FAULT = false, int EARLYZ = 0>
 __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> in, unsigned N, double Lx, double Ly, double Lz,
                                                                   DeviceParams prm, int L_typeid, SyncState st,
                                                                   uint64_t sequence, cavmd_result* __restrict__ res,
                                                                   HostResult* __restrict__ res_host,
-                                                                  v2d* __restrict__ force2, unsigned lds_slots, bool balanced)
+                                                                  v2d* __restrict__ force2, unsigned lds_slots, int balanced)
 {
     constexpr unsigned TILE = BLOCK * UNROLL; // particles per tile; the same tile is 2 * TILE force chunks
     constexpr int MU = 2 * UNROLL;            // 16-byte chunk stores per thread and tile
@@ -287,6 +308,30 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     __shared__ __attribute__((aligned(8))) unsigned s_words[kGroup * kGranulesPerRecord];
     unsigned long long* const block_slab = st.granules;
     unsigned long long* const group_slab = st.granules + (size_t)kMaxPersistGrid * kGranulesPerRecord;
+    if constexpr (EARLYZ != 0)
+    {
+        // waves 1 .. BLOCK/64 - 1: the (F_z, w) chunks of this block's tiles, tile by tile round-robin over those waves; a wave
+        // instruction stores 64 chunks 32 bytes apart (the odd halves of 2 KiB of force entries)
+        constexpr unsigned ZW = BLOCK / kWave - 1;
+        if (tid >= kWave)
+        {
+            const unsigned w = tid / kWave - 1, lane = tid % kWave;
+            const v2d z = {0.0, 0.0};
+            for (unsigned slot = w; slot < rg.nfull; slot += ZW)
+            {
+                v2d* const f = force2 + 2 * (rg.first + (size_t)slot * rg.step) + 1;
+#pragma unroll
+                for (unsigned j = 0; j < TILE / kWave; ++j)
+                    store_chunk<(EARLYZ == 2 ? 1 : 0)>(f + 2 * (size_t)(j * kWave + lane), z);
+            }
+            if (rg.tail_count && w == rg.nfull % ZW)
+            {
+                v2d* const f = force2 + 2 * rg.tail_base + 1;
+                for (unsigned o = lane; o < rg.tail_count; o += kWave)
+                    store_chunk<(EARLYZ == 2 ? 1 : 0)>(f + 2 * (size_t)o, z);
+            }
+        }
+    }
     if (tid < kWave)
     {
         bool ok = true;
@@ -481,6 +526,45 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
 
     const double ng = -prm.g;
     const size_t pchunk = 2 * (size_t)m.photon; // photon's first chunk
+    if constexpr (EARLYZ != 0)
+    {
+        // the even chunks only: lane = particle, charges straight from LDS (or re-read beyond the LDS budget); the photon's
+        // lane also writes its odd chunk (F_z, 0) over the zero of the early pass (same workgroup, after the barrier above)
+        auto put = [&](size_t p, double c) {
+            const double s = ng * c;
+            v2d v = {s * m.Dqx, s * m.Dqy};
+            if (p == (size_t)m.photon)
+            {
+                v = (v2d) {m.Fx, m.Fy};
+                store_chunk<NT_STORE>(force2 + 2 * p + 1, (v2d) {m.Fz, 0.0});
+            }
+            store_chunk<NT_STORE>(force2 + 2 * p, v);
+        };
+        for (unsigned slot = 0; slot < rg.nfull; ++slot)
+        {
+            const size_t p0 = rg.first + (size_t)slot * rg.step + tid;
+            double c[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                c[u] = slot < lds_slots ? s_charge[slot * TILE + u * BLOCK + tid]
+                                        : __builtin_nontemporal_load(in.charge + p0 + (size_t)u * BLOCK);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                put(p0 + (size_t)u * BLOCK, c[u]);
+        }
+        if (rg.tail_count)
+        {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+            {
+                const unsigned o = u * BLOCK + tid;
+                if (o < rg.tail_count)
+                    put(rg.tail_base + o, rg.nfull < lds_slots ? s_charge[rg.nfull * TILE + o] : in.charge[rg.tail_base + o]);
+            }
+        }
+        CAVMD_PSTAMP(6);
+        return;
+    }
     const bool odd = tid & 1;                   // BLOCK is even, so the half is fixed per thread
     auto store_tile = [&](unsigned slot, const double (&c)[MU]) {
         const size_t base = 2 * (rg.first + (size_t)slot * rg.step) + tid;

@@ -111,7 +111,8 @@ int main(int argc, char** argv)
     while (unroll > 1 && N / ((size_t)256 * unroll) < (size_t)CU * 5 / 4)
         unroll >>= 1;
     const bool nts = N >= 200000;
-#define ALLOW(UNR, NTS) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+#define ALLOW1(UNR, NTS, EZ) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<256, UNR, NTS, false, EZ>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+#define ALLOW(UNR, NTS) do { ALLOW1(UNR, NTS, 0); ALLOW1(UNR, NTS, 1); ALLOW1(UNR, NTS, 2); } while (0)
     ALLOW(1, false); ALLOW(1, true); ALLOW(2, false); ALLOW(2, true);
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<512, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -201,20 +202,27 @@ int main(int argc, char** argv)
                      else
                          hipLaunchKernelGGL((force_map_aos_fused_kernel<256, 4, false>), dim3(g2), dim3(256), 0, st, in0(f), n, g1, L, L, L, P, 2, part, 1ull, d_res, d_hres, (v2d*)d_frc[f], false);
                  }, {}});
-    auto persist = [&](int f, int bpc, bool balanced = false) {
+    auto persist = [&](int f, int bpc, int balanced = 0, int earlyz = 0) {
         const unsigned g1 = grid(N, 256 * unroll, bpc);
         const size_t tile = 256 * unroll;
         size_t slots = ((N + tile - 1) / tile + g1 - 1) / g1;
-        if (balanced) { const size_t units = (N + 63) / 64; slots = (((units + g1 - 1) / g1) * 64 + tile - 1) / tile; }
+        if (balanced == 1) { const size_t units = (N + 63) / 64; slots = (((units + g1 - 1) / g1) * 64 + tile - 1) / tile; }
+        if (balanced == 2) slots = (N / tile) / g1 + 1;
         const size_t cap = (156 * 1024 - 1024) / (tile * 8);
         const unsigned lds_slots = (unsigned)std::min(slots, cap);
         const size_t lds = (size_t)lds_slots * tile * 8;
-#define PL(UNR, NTS) hipLaunchKernelGGL((cavity_persistent_kernel<256, UNR, NTS>), dim3(g1), dim3(256), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f], lds_slots, balanced)
-        if (unroll == 2) { if (nts) PL(2, true); else PL(2, false); }
-        else { if (nts) PL(1, true); else PL(1, false); }
+#define PL(UNR, NTS, EZ) hipLaunchKernelGGL((cavity_persistent_kernel<256, UNR, NTS, false, EZ>), dim3(g1), dim3(256), lds, st, in2(f), n, L, L, L, P, 2, sync, 1ull, d_res, d_hres, (v2d*)d_frc[f], lds_slots, balanced)
+#define PLZ(UNR, NTS) do { if (earlyz == 0) PL(UNR, NTS, 0); else if (earlyz == 1) PL(UNR, NTS, 1); else PL(UNR, NTS, 2); } while (0)
+        if (unroll == 2) { if (nts) PLZ(2, true); else PLZ(2, false); }
+        else { if (nts) PLZ(1, true); else PLZ(1, false); }
     };
-    V.push_back({"single launch, tiles dealt round-robin", [&](int f) { persist(f, 1, false); }, {}});
-    V.push_back({"single launch, balanced contiguous shares", [&](int f) { persist(f, 1, true); }, {}});
+    V.push_back({"single launch, tiles dealt round-robin", [&](int f) { persist(f, 1, 0); }, {}});
+    V.push_back({"single launch, balanced contiguous shares", [&](int f) { persist(f, 1, 1); }, {}});
+    V.push_back({"single launch, full rounds strided + last round split evenly", [&](int f) { persist(f, 1, 2); }, {}});
+    if (getenv("CAVMD_TRY_EARLYZ")) {
+        V.push_back({"single launch, zero chunks early (plain stores)", [&](int f) { persist(f, 1, 0, 1); }, {}});
+        V.push_back({"single launch, zero chunks early (nt stores)", [&](int f) { persist(f, 1, 0, 2); }, {}});
+    }
     auto persist512 = [&](int f, int unr) {
         const size_t tile = 512 * unr;
         const unsigned g1 = grid(N, tile, 1);
@@ -230,6 +238,29 @@ int main(int argc, char** argv)
         V.push_back({"single launch, 512 threads x 2", [&](int f) { persist512(f, 2); }, {}});
     }
 
+    {
+        // every variant must give the bits of the first one (the product's two-launch path) in every force entry -- except the
+        // variants that partition the particles differently (other summation grouping: last bits of the dipole may differ)
+        std::vector<double> want(4 * N), got(4 * N);
+        for (size_t vi = 0; vi < V.size(); ++vi)
+        {
+            CHECK(hipMemset(d_frc[0], 0x5A, 32 * N));
+            V[vi].launch(0);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy((vi == 0 ? want : got).data(), d_frc[0], 32 * N, hipMemcpyDeviceToHost));
+            if (vi > 0)
+            {
+                size_t differ = 0; double worst = 0;
+                for (size_t i = 0; i < got.size(); ++i)
+                {
+                    differ += memcmp(&got[i], &want[i], 8) != 0;
+                    const double d = got[i] - want[i], sc = want[i] < 0 ? -want[i] : want[i];
+                    if (sc > 0 && (d < 0 ? -d : d) / sc > worst) worst = (d < 0 ? -d : d) / sc;
+                }
+                printf("check %-60s entries differing from two launches: %zu of %zu (worst relative %.1e)\n", V[vi].name.c_str(), differ, got.size(), worst);
+            }
+        }
+    }
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     int frame = 0;
@@ -257,6 +288,9 @@ int main(int argc, char** argv)
     }
 
     // ---- time line of the single-launch kernel: per-block stamps, relative to the first block's start ----------------------
+    const int timeline_earlyz = getenv("CAVMD_TIMELINE_EARLYZ") ? atoi(getenv("CAVMD_TIMELINE_EARLYZ")) : 0;
+    const int timeline_partition = getenv("CAVMD_TIMELINE_PARTITION") ? atoi(getenv("CAVMD_TIMELINE_PARTITION")) : 0;
+    printf("time line of the variant with partition %d, EARLYZ %d\n", timeline_partition, timeline_earlyz);
     for (int mode = 0; mode < 1; ++mode)
     {
         const unsigned g1 = grid(N, 256 * unroll, 1);
@@ -265,7 +299,7 @@ int main(int argc, char** argv)
         std::vector<std::vector<double>> med(8), mx(8), mnv(8);
         for (int rep = 0; rep < 30; ++rep)
         {
-            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, false); // steady state: the stamps are those of the last launch
+            for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, timeline_partition, timeline_earlyz); // steady state: the stamps are those of the last launch
             CHECK(hipDeviceSynchronize());
             std::vector<unsigned long long> h(4096 * kStampSlots);
             CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
