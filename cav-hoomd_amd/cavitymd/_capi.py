@@ -61,11 +61,19 @@ class BussiReservoirState(ctypes.Structure):
                 ("instantaneous_translational", ctypes.c_double), ("instantaneous_rotational", ctypes.c_double)]
 
 
+class BussiDeviceState(ctypes.Structure):
+    """cavmd_bussi_device_state: the on-device thermostat's counters after its last step."""
+    _fields_ = [("reservoir_translational", ctypes.c_double), ("instantaneous_translational", ctypes.c_double),
+                ("last_alpha", ctypes.c_double), ("last_kinetic_energy", ctypes.c_double), ("steps", ctypes.c_uint64),
+                ("refused", ctypes.c_uint64)]
+
+
 # every symbol include/cavmd.h exports; tests check the header and the library against this list
 EXPORTED_SYMBOLS = (
     "cavmd_make_params", "cavmd_create", "cavmd_destroy", "cavmd_compute_hoomd", "cavmd_compute_soa",
     "cavmd_energies", "cavmd_result_read", "cavmd_result_device_ptr", "cavmd_set_wavevectors", "cavmd_density_field",
     "cavmd_density_field_read", "cavmd_cavity_mode", "cavmd_force_mass_sum", "cavmd_kinetic_energy", "cavmd_scale_velocities",
+    "cavmd_bussi_step_device", "cavmd_bussi_device_read", "cavmd_bussi_device_reset",
     "cavmd_bussi_rescale_factor", "cavmd_bussi_step", "cavmd_profile_enable", "cavmd_profile_read", "cavmd_profile_samples",
     "cavmd_set_tunable", "cavmd_get_tunable", "cavmd_device_info", "cavmd_error_string", "cavmd_version",
 )
@@ -134,6 +142,12 @@ def load():
         lib.cavmd_bussi_rescale_factor.restype = ci
         lib.cavmd_bussi_step.argtypes = [P(BussiReservoirState), dbl, dbl, dbl, dbl, dbl, dbl, dbl, P(dbl * 4), P(dbl * 2)]
         lib.cavmd_bussi_step.restype = ci
+        lib.cavmd_bussi_step_device.argtypes = [vp, vp, vp, vp, sz] + [dbl] * 6
+        lib.cavmd_bussi_step_device.restype = ci
+        lib.cavmd_bussi_device_read.argtypes = [vp, vp, P(BussiDeviceState)]
+        lib.cavmd_bussi_device_read.restype = ci
+        lib.cavmd_bussi_device_reset.argtypes = [vp, vp]
+        lib.cavmd_bussi_device_reset.restype = ci
         lib.cavmd_profile_enable.argtypes = [vp, ci]
         lib.cavmd_profile_enable.restype = ci
         lib.cavmd_profile_read.argtypes = [vp, P(dbl * 3), P(ctypes.c_uint64)]
@@ -286,6 +300,22 @@ class Workspace:
         check(self._lib.cavmd_scale_velocities(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr),
                                                ctypes.c_void_p(members_ptr) if members_ptr else None, int(n_members),
                                                float(alpha)), "cavmd_scale_velocities")
+
+    def bussi_step_device(self, stream: int, vel_ptr: int, members_ptr, n_members: int, dof: float, deltaT: float, set_T: float,
+                          tau: float, normal_variate: float, gamma_variate: float) -> None:
+        """One translational thermostat step on the device, asynchronous (two kernels, no host round trip)."""
+        check(self._lib.cavmd_bussi_step_device(self._h, ctypes.c_void_p(stream), ctypes.c_void_p(vel_ptr),
+                                                ctypes.c_void_p(members_ptr) if members_ptr else None, int(n_members),
+                                                float(dof), float(deltaT), float(set_T), float(tau), float(normal_variate),
+                                                float(gamma_variate)), "cavmd_bussi_step_device")
+
+    def bussi_device_read(self, stream: int = 0) -> "BussiDeviceState":
+        out = BussiDeviceState()
+        check(self._lib.cavmd_bussi_device_read(self._h, ctypes.c_void_p(stream), ctypes.byref(out)), "cavmd_bussi_device_read")
+        return out
+
+    def bussi_device_reset(self, stream: int = 0) -> None:
+        check(self._lib.cavmd_bussi_device_reset(self._h, ctypes.c_void_p(stream)), "cavmd_bussi_device_reset")
 
     # -- measurement / tuning -----------------------------------------------------------------------
     def profile_enable(self, on: bool) -> None:

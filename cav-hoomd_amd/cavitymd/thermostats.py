@@ -13,7 +13,8 @@ Same constructor and read-only properties as the reference:
 Inside HOOMD the thermostat is driven by the integration method (``getRescalingFactorsOne``).  HOOMD-blue is absent here,
 so ``step`` below plays that caller for the standalone harness: kinetic energy of the group on the GPU
 (``cavmd_kinetic_energy``), the scalar rule with its sign handling and the reservoir bookkeeping (``cavmd_bussi_step``),
-and the velocity rescaling HOOMD's integration method would apply (``cavmd_scale_velocities``).
+and the velocity rescaling HOOMD's integration method would apply (``cavmd_scale_velocities``).  ``step_async`` does the same
+translational step entirely on the device (``cavmd_bussi_step_device``): two kernels, no host round trip, counters fetched lazily.
 
 The two random variates per degree-of-freedom class come from the caller (``variates=``) or from a
 ``numpy.random.Generator``.  The reference draws them from HOOMD's RandomGenerator seeded by (timestep, simulation seed,
@@ -82,10 +83,38 @@ class BussiReservoir:
             variates = draw_variates(rng, translational_dof, rotational_dof)
         at, ar = _capi.bussi_step(self._state, ke, translational_dof, rotational_kinetic_energy, rotational_dof, deltaT,
                                   self._set_T(timestep), self.tau, variates)
+        self._last_on_device = False
         if rescale and deltaT != 0.0:
             mp = self._members.data_ptr() if self._members is not None else None
             self._ws.scale_velocities(self._stream(velocity, stream), velocity.data_ptr(), mp, self._n_members, at)
         return at, ar
+
+    def step_async(self, timestep: int, deltaT: float, velocity: torch.Tensor, translational_dof: float, variates=None,
+                   rng=None, stream=None) -> None:
+        """The translational step without a host round trip: the kernel that folds the kinetic energy evaluates the rule on
+        the device and leaves alpha for the rescale kernel enqueued right behind it; nothing is waited for.  The counters are
+        fetched when a property is read.  (Rotational degrees of freedom are not handled on this path: use ``step``.)"""
+        if not self._attached:
+            raise RuntimeError("BussiReservoir.step_async before attach()")
+        if velocity.dtype != torch.float64 or velocity.dim() != 2 or velocity.shape[1] != 4 or not velocity.is_contiguous():
+            raise ValueError("velocity must be a contiguous (N,4) float64 tensor (HOOMD Scalar4, mass in .w)")
+        if variates is None:
+            rng = rng if rng is not None else np.random.default_rng()
+            variates = draw_variates(rng, translational_dof, 0.0)
+        mp = self._members.data_ptr() if self._members is not None else None
+        self._dev_stream = self._stream(velocity, stream)
+        self._ws.bussi_step_device(self._dev_stream, velocity.data_ptr(), mp, self._n_members, translational_dof, deltaT,
+                                   self._set_T(timestep), self.tau, variates[0], variates[1])
+        if deltaT != 0.0 and self._n_members:
+            self._dev_used = True
+            self._last_on_device = True
+
+    def device_state(self):
+        """Counters of the on-device path after its last enqueued step (waits for that step's flag, nothing else)."""
+        return self._ws.bussi_device_read(getattr(self, "_dev_stream", 0))
+
+    def _dev(self, field: str) -> float:
+        return getattr(self.device_state(), field) if getattr(self, "_dev_used", False) else 0.0
 
     @staticmethod
     def _stream(t: torch.Tensor, stream) -> int:
@@ -96,7 +125,7 @@ class BussiReservoir:
     # -- the reference's loggable quantities ---------------------------------------------------------------------------------
     @property
     def reservoir_energy_translational(self) -> float:
-        return self._state.reservoir_translational if self._attached else 0.0
+        return (self._state.reservoir_translational + self._dev("reservoir_translational")) if self._attached else 0.0
 
     @property
     def reservoir_energy_rotational(self) -> float:
@@ -104,11 +133,15 @@ class BussiReservoir:
 
     @property
     def total_reservoir_energy(self) -> float:
-        return (self._state.reservoir_translational + self._state.reservoir_rotational) if self._attached else 0.0
+        return (self.reservoir_energy_translational + self._state.reservoir_rotational) if self._attached else 0.0
 
     @property
     def instantaneous_reservoir_translational(self) -> float:
-        return self._state.instantaneous_translational if self._attached else 0.0
+        if not self._attached:
+            return 0.0
+        if getattr(self, "_last_on_device", False):
+            return self._dev("instantaneous_translational")
+        return self._state.instantaneous_translational
 
     @property
     def instantaneous_reservoir_rotational(self) -> float:
@@ -116,10 +149,12 @@ class BussiReservoir:
 
     @property
     def instantaneous_reservoir_total(self) -> float:
-        return (self._state.instantaneous_translational + self._state.instantaneous_rotational) if self._attached else 0.0
+        return (self.instantaneous_reservoir_translational + self.instantaneous_reservoir_rotational) if self._attached else 0.0
 
     def reset_reservoir_energy(self) -> None:
         self._state = _capi.BussiReservoirState()
+        if getattr(self, "_dev_used", False):
+            self._ws.bussi_device_reset(getattr(self, "_dev_stream", 0))
 
 
 def draw_variates(rng: np.random.Generator, translational_dof: float, rotational_dof: float = 0.0):

@@ -127,6 +127,12 @@ struct cavmd_workspace
     HostScalar* h_fm_dev = nullptr; // device-side address of h_fm
     uint64_t fm_sequence = 0;
     unsigned* d_fm_ticket = nullptr; // ticket counter of the one-launch scalar reductions (reset by the folding block)
+    // on-device Bussi thermostat (cavmd_bussi_step_device)
+    BussiDevice* d_bussi = nullptr;
+    HostBussi* h_bussi = nullptr;     // pinned, mapped, coherent
+    HostBussi* h_bussi_dev = nullptr;
+    uint64_t bussi_sequence = 0;
+    uint64_t bussi_refused_seen = 0;  // refusals already reported to the caller
 };
 
 namespace
@@ -266,7 +272,12 @@ int wait_scalar(cavmd_workspace* ws, hipStream_t stream, double* out)
         if (q == hipSuccess)
         {
             if (__atomic_load_n(&ws->h_fm->ready, __ATOMIC_ACQUIRE) != want)
+            {
+                // the kernel never published (failed or aborted launch): its blocks may have left the ticket counter
+                // part-way, after which no block would ever be "last" again -- put it back before reporting
+                (void)hipMemsetAsync(ws->d_fm_ticket, 0, 128, stream);
                 return (int)hipErrorLaunchFailure;
+            }
             break;
         }
         if (q != hipErrorNotReady)
@@ -483,6 +494,10 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipHostFree(ws->h_fm);
     if (ws->d_fm_ticket)
         (void)hipFree(ws->d_fm_ticket);
+    if (ws->d_bussi)
+        (void)hipFree(ws->d_bussi);
+    if (ws->h_bussi)
+        (void)hipHostFree(ws->h_bussi);
     delete ws;
     return CAVMD_OK;
 }
@@ -1148,27 +1163,10 @@ int cavmd_bussi_rescale_factor(double K, double degrees_of_freedom, double delta
 {
     if (!alpha)
         return CAVMD_ERR_INVALID_VALUE;
-    // src/BussiReservoirThermostat.h:183-184
-    if (degrees_of_freedom == 0)
-    {
-        *alpha = 1.0;
-        return CAVMD_OK;
-    }
-    // :186-190  c = exp(-dt / tau), 0 for tau == 0 (instantaneous thermalisation)
+    // src/BussiReservoirThermostat.h:186-190  c = exp(-dt / tau), 0 for tau == 0 (instantaneous thermalisation); the rest of
+    // the rule (:183-213) is bussi_alpha_from_c, the function the on-device step runs too
     const double c = (tau != 0.0) ? exp(-deltaT / tau) : 0.0;
-    // :192-199  R ~ N(0,1); the sum of the other dof - 1 squared normals is 2 * Gamma((dof - 1) / 2, 1)
-    const double R = normal_variate;
-    const double r_gamma = (degrees_of_freedom > 1.0) ? 2.0 * gamma_variate : 0.0;
-    // :201-203
-    const double v = set_T / 2.0 / K;
-    const double term1 = v * (1.0 - c) * (r_gamma + R * R);
-    const double term2 = 2.0 * R * sqrt(v * (1.0 - c) * c);
-    // :206-207
-    const double magnitude = sqrt(c + term1 + term2);
-    // :211-213  sign[alpha] = sign[R + sqrt(c Nf K / ((1 - c) Kbar))], Bussi et al. 2009, eq. (A8)
-    const double K_bar = set_T * degrees_of_freedom / 2.0;
-    const double sign_term = R + sqrt(c * degrees_of_freedom * K / ((1.0 - c) * K_bar));
-    *alpha = (sign_term >= 0.0) ? magnitude : -magnitude;
+    *alpha = bussi_alpha_from_c(K, degrees_of_freedom, c, set_T, normal_variate, gamma_variate);
     return CAVMD_OK;
 }
 
@@ -1199,6 +1197,120 @@ int cavmd_bussi_step(cavmd_bussi_reservoir* state, double K_translational, doubl
     state->instantaneous_rotational = delta_r;
     factors[0] = at;
     factors[1] = ar;
+    return CAVMD_OK;
+}
+
+namespace
+{
+int ensure_bussi_state(cavmd_workspace* ws)
+{
+    if (ws->d_bussi)
+        return CAVMD_OK;
+    CAVMD_HIP_TRY(hipMalloc((void**)&ws->d_bussi, sizeof(BussiDevice)));
+    CAVMD_HIP_TRY(hipMemset(ws->d_bussi, 0, sizeof(BussiDevice)));
+    CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_bussi, sizeof(HostBussi), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ws->h_bussi, 0, sizeof(HostBussi));
+    CAVMD_HIP_TRY(hipHostGetDevicePointer((void**)&ws->h_bussi_dev, ws->h_bussi, 0));
+    return CAVMD_OK;
+}
+} // namespace
+
+int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream_, cavmd_double4* d_vel, const uint32_t* d_members,
+                            size_t n_members, double dof_translational, double deltaT, double set_T, double tau,
+                            double normal_variate, double gamma_variate)
+{
+    if (!ws || !d_vel || ((uintptr_t)d_vel & 15) || ((uintptr_t)d_members & 3))
+        return CAVMD_ERR_INVALID_VALUE;
+    if (n_members > (size_t)INT_MAX)
+        return CAVMD_ERR_CAPACITY;
+    if (deltaT == 0.0 || n_members == 0) // src/BussiReservoirThermostat.h:45-48: factors {1, 1}, counters untouched
+        return CAVMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    {
+        int st0 = ensure_scalar_scratch(ws);
+        if (st0 == CAVMD_OK)
+            st0 = ensure_bussi_state(ws);
+        if (st0 != CAVMD_OK)
+            return st0;
+    }
+    constexpr int kBlock = 256, kUnroll = 4;
+    BussiStepArgs a;
+    a.dof = dof_translational;
+    a.c = (tau != 0.0) ? exp(-deltaT / tau) : 0.0; // :186-190
+    a.set_T = set_T;
+    a.normal_variate = normal_variate;
+    a.gamma_variate = gamma_variate;
+    const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 1);
+    ws->bussi_sequence += 1;
+    hipLaunchKernelGGL((bussi_kinetic_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, ws->d_fm_ticket, a,
+                       ws->d_bussi, ws->h_bussi_dev, ws->bussi_sequence);
+    CAVMD_HIP_TRY(hipGetLastError());
+    const unsigned g2 = grid_for(n_members, kBlock, ws->num_cu, 8);
+    hipLaunchKernelGGL((scale_velocities_dev_kernel<kBlock>), dim3(g2), dim3(kBlock), 0, stream, reinterpret_cast<v2d*>(d_vel),
+                       d_members, (unsigned)n_members, ws->d_bussi);
+    return hip_status(hipGetLastError());
+}
+
+int cavmd_bussi_device_read(cavmd_workspace* ws, void* stream_, cavmd_bussi_device_state* out)
+{
+    if (!ws || !out)
+        return CAVMD_ERR_INVALID_VALUE;
+    memset(out, 0, sizeof(*out));
+    if (!ws->d_bussi || ws->bussi_sequence == 0)
+        return CAVMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    const uint64_t want = ws->bussi_sequence;
+    for (;;)
+    {
+        if (__atomic_load_n(&ws->h_bussi->ready, __ATOMIC_ACQUIRE) == want)
+            break;
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess)
+        {
+            if (__atomic_load_n(&ws->h_bussi->ready, __ATOMIC_ACQUIRE) != want)
+            {
+                (void)hipMemsetAsync(ws->d_fm_ticket, 0, 128, stream); // as wait_scalar: a launch that never published
+                return (int)hipErrorLaunchFailure;
+            }
+            break;
+        }
+        if (q != hipErrorNotReady)
+            return (int)q;
+    }
+    const BussiDevice s = ws->h_bussi->state;
+    out->reservoir_translational = s.reservoir;
+    out->instantaneous_translational = s.instantaneous;
+    out->last_alpha = s.alpha;
+    out->last_kinetic_energy = s.kinetic;
+    out->steps = s.steps;
+    out->refused = s.errors;
+    if (s.errors != ws->bussi_refused_seen)
+    {
+        ws->bussi_refused_seen = s.errors;
+        return CAVMD_ERR_BAD_PARAMS; // "Bussi thermostat requires non-zero initial momenta."
+    }
+    return CAVMD_OK;
+}
+
+int cavmd_bussi_device_reset(cavmd_workspace* ws, void* stream_)
+{
+    if (!ws)
+        return CAVMD_ERR_INVALID_VALUE;
+    if (!ws->d_bussi)
+        return CAVMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DeviceGuard guard(ws->device);
+    // wait for the last step's publication first so that the host copy can be reset consistently
+    cavmd_bussi_device_state unused;
+    const int st = cavmd_bussi_device_read(ws, stream_, &unused);
+    if (st != CAVMD_OK && st != CAVMD_ERR_BAD_PARAMS)
+        return st;
+    CAVMD_HIP_TRY(hipMemsetAsync(ws->d_bussi, 0, sizeof(BussiDevice), stream));
+    memset(&ws->h_bussi->state, 0, sizeof(BussiDevice));
+    ws->bussi_refused_seen = 0;
     return CAVMD_OK;
 }
 

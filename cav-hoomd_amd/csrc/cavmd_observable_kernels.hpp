@@ -234,7 +234,12 @@ __global__ __launch_bounds__(BLOCK) void density_partials_lp_kernel(const char* 
         ksum = fmax(ksum, (fabs(kv[0]) + fabs(kv[1])) + fabs(kv[2]));
     }
     // the chunk's wavevectors, loaded once: uniform values, so they live in SGPRs (a padded kk of the last, partial chunk
-    // repeats the chunk's first wavevector; it is never stored)
+    // repeats the chunk's first wavevector; it is never stored).  6 KC SGPRs next to the 30 of the sincos coefficients do not
+    // all fit the ~100 a wave has: hipcc parks 9 / 41 / 141 of them in VGPR lanes at KC = 5 / 10 / 25 (v_readlane in the tile
+    // loop, no scratch memory).  Round 3 measured the alternative -- fetching the wavevectors again for every tile through the
+    // scalar cache (pointer laundered so the loads stay in the loop: 0 / 3 / 18 spills) -- and it is SLOWER: 57.5 vs 53 us at
+    // n_k = 17 and 113.6 vs 95 us at n_k = 50 (KC = 5, N = 1e6; profiles/r03/ab_density_reload_wavevectors.txt): a
+    // v_readlane costs one issue slot, a scalar load a round trip the short tile (KC sincos) cannot hide.  The spills stay.
     double kx[KC], ky[KC], kz[KC];
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
@@ -511,6 +516,8 @@ __global__ __launch_bounds__(BLOCK) void force_mass_fused_kernel(const v2d* __re
             const v2d zero = {0.0, 0.0}, one = {0.0, 1.0};
             fxy[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i) : zero;
             fzw[u] = ok ? __builtin_nontemporal_load(force2 + 2 * i + 1) : zero;
+            // the mass sits in vel.w: only the (vz, m) half of each velocity entry is asked for.  (Asking for the (vx, vy) half
+            // as well, so that the wave's loads cover whole lines, measured slower: 19.1 vs 17.5 us at N = 1e6, round 3.)
             vzw[u] = ok ? __builtin_nontemporal_load(vel2 + 2 * i + 1) : one;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -542,11 +549,9 @@ __global__ __launch_bounds__(BLOCK) void force_mass_fused_kernel(const v2d* __re
 // =====================================================================================================================
 namespace cavmd
 {
+// sum_j m_j (vx^2 + vy^2 + vz^2) over this block's tiles (tile t -> block t % gridDim.x), one double-double per lane
 template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
-                                                              unsigned n, double* __restrict__ part,
-                                                              unsigned* __restrict__ ticket, double* __restrict__ out,
-                                                              HostScalar* __restrict__ host, uint64_t sequence)
+__device__ __forceinline__ DD kinetic_partial(const v2d* __restrict__ vel2, const unsigned* __restrict__ members, unsigned n)
 {
     constexpr unsigned TILE = BLOCK * UNROLL;
     DD acc {0.0, 0.0};
@@ -570,6 +575,16 @@ __global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restr
         for (int u = 0; u < UNROLL; ++u)
             dd_acc(acc.hi, acc.lo, vzw[u].y * ((vxy[u].x * vxy[u].x + vxy[u].y * vxy[u].y) + vzw[u].x * vzw[u].x));
     }
+    return acc;
+}
+
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                              unsigned n, double* __restrict__ part,
+                                                              unsigned* __restrict__ ticket, double* __restrict__ out,
+                                                              HostScalar* __restrict__ host, uint64_t sequence)
+{
+    DD acc = kinetic_partial<BLOCK, UNROLL>(vel2, members, n);
     acc = block_reduce_dd1<BLOCK>(acc);
     if (fold_by_last_block<BLOCK>(acc, part, ticket) && threadIdx.x == 0)
     {
@@ -578,11 +593,106 @@ __global__ __launch_bounds__(BLOCK) void kinetic_fused_kernel(const v2d* __restr
     }
 }
 
+// ---- the whole translational thermostat step on the device (round 3) --------------------------------------------------------
+// The rule of compute_rescale_factor (src/BussiReservoirThermostat.h:177-225) with c = exp(-dt / tau) supplied by the caller
+// (it depends on host parameters only; everything else is +, -, *, /, sqrt, correctly rounded on host and device alike, and
+// this file is built with -ffp-contract=off): the host entry point cavmd_bussi_rescale_factor and the kernel below run this
+// very function, so they give the same bits for the same kinetic energy.
+__host__ __device__ inline double bussi_alpha_from_c(double K, double degrees_of_freedom, double c, double set_T, double R,
+                                                     double gamma_variate)
+{
+    if (degrees_of_freedom == 0) // :183-184
+        return 1.0;
+    const double r_gamma = (degrees_of_freedom > 1.0) ? 2.0 * gamma_variate : 0.0; // :192-199
+    const double v = set_T / 2.0 / K;                                              // :201-203
+    const double term1 = v * (1.0 - c) * (r_gamma + R * R);
+    const double term2 = 2.0 * R * sqrt(v * (1.0 - c) * c);
+    const double magnitude = sqrt(c + term1 + term2);                              // :206-207
+    const double K_bar = set_T * degrees_of_freedom / 2.0;                         // :211-213, Bussi et al. 2009 eq. (A8)
+    const double sign_term = R + sqrt(c * degrees_of_freedom * K / ((1.0 - c) * K_bar));
+    return (sign_term >= 0.0) ? magnitude : -magnitude;
+}
+
+// State of the on-device thermostat (device memory; a copy goes to mapped host memory after every step).
+struct BussiDevice
+{
+    double reservoir;     // cumulative energy handed to the bath, sum of KE (1 - alpha^2)   (src/BussiReservoirThermostat.h:86-95)
+    double instantaneous; // the last step's share
+    double alpha;         // the last step's factor: what the rescale kernel of the same step reads
+    double kinetic;       // the kinetic energy the last step saw
+    uint64_t steps;       // steps applied
+    uint64_t errors;      // steps refused: degrees of freedom without kinetic energy ("requires non-zero initial momenta", :57-61)
+};
+struct HostBussi
+{
+    BussiDevice state;
+    uint64_t ready; // sequence number of the step `state` belongs to
+};
+struct BussiStepArgs
+{
+    double dof, c, set_T, normal_variate, gamma_variate;
+};
+
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void bussi_kinetic_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                              unsigned n, double* __restrict__ part,
+                                                              unsigned* __restrict__ ticket, BussiStepArgs a,
+                                                              BussiDevice* __restrict__ state, HostBussi* __restrict__ host,
+                                                              uint64_t sequence)
+{
+    DD acc = kinetic_partial<BLOCK, UNROLL>(vel2, members, n);
+    acc = block_reduce_dd1<BLOCK>(acc);
+    if (fold_by_last_block<BLOCK>(acc, part, ticket) && threadIdx.x == 0)
+    {
+        const double K = 0.5 * (acc.hi + acc.lo);
+        BussiDevice s = *state;
+        s.kinetic = K;
+        if (a.dof != 0 && K == 0)
+        {
+            s.alpha = 1.0; // nothing is rescaled, the refusal is counted and reported by cavmd_bussi_device_read
+            s.instantaneous = 0.0;
+            s.errors += 1;
+        }
+        else
+        {
+            s.alpha = bussi_alpha_from_c(K, a.dof, a.c, a.set_T, a.normal_variate, a.gamma_variate);
+            const double delta = K * (1.0 - s.alpha * s.alpha);
+            s.reservoir += delta;
+            s.instantaneous = delta;
+            s.steps += 1;
+        }
+        *state = s; // the rescale kernel behind this one (same stream) reads alpha from here
+        host->state = s;
+        __hip_atomic_store(&host->ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // v_j.xyz *= alpha for the members of the group (mass in .w untouched)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void scale_velocities_kernel(v2d* __restrict__ vel2, const unsigned* __restrict__ members,
                                                                  unsigned n, double alpha)
 {
+    for (size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (size_t)gridDim.x * BLOCK)
+    {
+        const size_t j = members ? (size_t)members[k] : k;
+        v2d xy = vel2[2 * j], zw = vel2[2 * j + 1];
+        xy.x *= alpha;
+        xy.y *= alpha;
+        zw.x *= alpha;
+        vel2[2 * j] = xy;
+        vel2[2 * j + 1] = zw;
+    }
+}
+
+// the same with alpha read from the thermostat's device state (written by bussi_kinetic_kernel earlier in the stream);
+// alpha == 1 (dt == 0 or a refused step) leaves the array untouched -- multiplying by 1.0 would give the same bits
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void scale_velocities_dev_kernel(v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                                     unsigned n, const BussiDevice* __restrict__ state)
+{
+    const double alpha = state->alpha;
+    if (alpha == 1.0)
+        return;
     for (size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (size_t)gridDim.x * BLOCK)
     {
         const size_t j = members ? (size_t)members[k] : k;

@@ -19,7 +19,8 @@
  *   BussiReservoirThermostat::getRescalingFactorsOne / compute_rescale_factor
  *                               src/BussiReservoirThermostat.h:43-98, 177-225
  *                                                                   cavmd_bussi_step / cavmd_bussi_rescale_factor,
- *                                                                   cavmd_kinetic_energy, cavmd_scale_velocities
+ *                                                                   cavmd_kinetic_energy, cavmd_scale_velocities,
+ *                                                                   cavmd_bussi_step_device (the step without a host round trip)
  *   CavityForceCompute::computeForces (the CPU semantics both follow)
  *                               src/CavityForceCompute.cc:134-208   (semantic contract, see below)
  *
@@ -258,6 +259,32 @@ CAVMD_API int cavmd_bussi_rescale_factor(double K, double degrees_of_freedom, do
 CAVMD_API int cavmd_bussi_step(cavmd_bussi_reservoir* state, double K_translational, double dof_translational,
                                double K_rotational, double dof_rotational, double deltaT, double set_T, double tau,
                                const double variates[4], double factors[2]);
+
+/* The same translational step ENTIRELY ON THE DEVICE and asynchronous (round 3): kinetic energy of the group -> alpha ->
+ * reservoir counters -> velocities *= alpha, as two kernels enqueued on `stream` with no host round trip in between (the
+ * kernel that folds the kinetic energy evaluates the rule and leaves alpha in device memory for the rescale kernel).  What
+ * getRescalingFactorsOne + the integration method's rescale do per step (src/BussiReservoirThermostat.h:43-98, 177-225) for the
+ * translational degrees of freedom; rotational ones stay on the host path above (cavmd_bussi_step).  The rule runs the same
+ * source function as cavmd_bussi_rescale_factor (c = exp(-dt / tau) is taken on the host): same bits for the same kinetic energy.
+ * deltaT == 0 enqueues nothing (factors 1, counters untouched, :45-48).  Degrees of freedom with zero kinetic energy: the step
+ * is refused on the device (alpha = 1, nothing rescaled) and the NEXT cavmd_bussi_device_read returns CAVMD_ERR_BAD_PARAMS once. */
+CAVMD_API int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream, cavmd_double4* d_vel, const uint32_t* d_members,
+                                      size_t n_members, double dof_translational, double deltaT, double set_T, double tau,
+                                      double normal_variate, double gamma_variate);
+typedef struct cavmd_bussi_device_state
+{
+    double reservoir_translational;     /* cumulative, as cavmd_bussi_reservoir */
+    double instantaneous_translational; /* last step */
+    double last_alpha;                  /* the factor the last step applied */
+    double last_kinetic_energy;         /* the kinetic energy it saw (before rescaling) */
+    uint64_t steps;                     /* steps applied since creation / reset */
+    uint64_t refused;                   /* steps refused for zero kinetic energy */
+} cavmd_bussi_device_state;
+/* State after the last enqueued cavmd_bussi_step_device: spins on the flag that step publishes into mapped host memory (no
+ * copy, no stream synchronisation); before any step: zeros.  CAVMD_ERR_BAD_PARAMS (once) if a step was refused since the last call. */
+CAVMD_API int cavmd_bussi_device_read(cavmd_workspace* ws, void* stream, cavmd_bussi_device_state* out);
+/* reset_reservoir_energy() of the reference's Python class: zero the counters (ordered on `stream`). */
+CAVMD_API int cavmd_bussi_device_reset(cavmd_workspace* ws, void* stream);
 
 /* ---- measurement hooks (bench.py's roofline leg) ---------------------------------------------- */
 /* When enabled, every cavmd_compute_* brackets each of its kernels with hipEvents on `stream`. */

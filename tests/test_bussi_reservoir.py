@@ -182,3 +182,76 @@ def test_counters_start_at_zero_move_and_reset_over_1000_steps(bussi):
     assert th.reservoir_energy_rotational == 0.0 and th.total_reservoir_energy != 0.0
     th.reset_reservoir_energy()
     assert th.total_reservoir_energy == 0.0 and th.instantaneous_reservoir_total == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,grouped", [(1_025, False), (20_001, True), (300_001, False)])
+def test_on_device_step_is_the_host_step_bit_for_bit(bussi, n, grouped):
+    """cavmd_bussi_step_device (two kernels, no host round trip) against the host-driven step of the same library and
+    against the oracle: same kinetic energy bits (same kernel body and grid), same alpha bits (the rule is ONE source function
+    for host and device, c = exp(-dt/tau) taken on the host), same velocities, same counters -- step by step, including the
+    negative-alpha branch (tau = 0, R < 0) and dt = 0."""
+    vel = _velocities(n, seed=n + 1)
+    members = np.arange(n - 1, dtype=np.uint32) if grouped else None
+    nm = n - 1 if grouped else n
+    dof = 3.0 * nm - 3.0
+    a_vel, b_vel = torch.from_numpy(vel.copy()).cuda(), torch.from_numpy(vel.copy()).cuda()
+    host = thermostats.BussiReservoir(kT=3.167e-6 * 100, tau=0.5)
+    dev = thermostats.BussiReservoir(kT=3.167e-6 * 100, tau=0.5)
+    host.attach(n, members)
+    dev.attach(n, members)
+    rng = np.random.default_rng(7)
+    ref_state = np.zeros(4)
+    for step in range(60):
+        var = thermostats.draw_variates(rng, dof)
+        tau = 0.0 if step % 13 == 5 else 0.5
+        if step % 13 == 5:
+            var[0] = -abs(var[0]) - 0.1
+        dt = 0.0 if step == 20 else 0.02
+        host.tau = dev.tau = tau
+        ke_before = host.kinetic_energy(a_vel)
+        at, _ = host.step(step, dt, a_vel, dof, variates=var)
+        dev.step_async(step, dt, b_vel, dof, variates=var)
+        if step % 7 == 0 or step == 20:
+            st = dev.device_state()
+            if dt != 0.0:
+                assert st.last_kinetic_energy == ke_before and st.last_alpha == at          # bits
+                assert st.last_alpha == _capi.bussi_rescale_factor(ke_before, dof, dt, host.kT, tau, var[0], var[1])
+                want = bussi.step(ref_state.copy(), ke_before, dof, 0.0, 0.0, dt, host.kT, tau, var)
+                assert st.last_alpha == want[0]
+            assert dev.instantaneous_reservoir_translational == host.instantaneous_reservoir_translational or dt == 0.0
+            assert dev.reservoir_energy_translational == host.reservoir_energy_translational
+    torch.cuda.synchronize()
+    assert torch.equal(a_vel, b_vel)
+    st = dev.device_state()
+    assert st.steps == 59 and st.refused == 0                                                 # the dt = 0 step enqueued nothing
+    assert dev.total_reservoir_energy == host.total_reservoir_energy != 0.0
+    dev.reset_reservoir_energy()
+    assert dev.total_reservoir_energy == 0.0 and dev.device_state().steps == 0
+
+
+@pytest.mark.gpu
+def test_on_device_step_refuses_zero_momenta_and_keeps_the_array():
+    """Degrees of freedom without kinetic energy: the reference throws "requires non-zero initial momenta"
+    (src/BussiReservoirThermostat.h:57-61).  On the device the step is refused (alpha = 1, nothing rescaled) and the next read
+    of the state reports it once."""
+    n = 5_000
+    vel = np.zeros((n, 4))
+    vel[:, 3] = 2.0
+    dvel = torch.from_numpy(vel.copy()).cuda()
+    ws = _capi.Workspace(n)
+    ws.bussi_step_device(0, dvel.data_ptr(), None, n, 3.0 * n, 0.02, 3e-4, 0.5, 0.3, 7000.0)
+    with pytest.raises(_capi.CavmdError) as e:
+        ws.bussi_device_read(0)
+    assert e.value.status == _capi.CAVMD_ERR_BAD_PARAMS
+    st = ws.bussi_device_read(0)                                   # reported once
+    assert st.refused == 1 and st.steps == 0 and st.last_alpha == 1.0 and st.reservoir_translational == 0.0
+    torch.cuda.synchronize()
+    assert np.array_equal(dvel.cpu().numpy(), vel)
+    # dof == 0: alpha = 1 by the rule itself (:183-184), not an error
+    ws.bussi_step_device(0, dvel.data_ptr(), None, n, 0.0, 0.02, 3e-4, 0.5, 0.3, 0.0)
+    st = ws.bussi_device_read(0)
+    assert st.steps == 1 and st.last_alpha == 1.0
+    # argument validation, as the other entry points
+    with pytest.raises(_capi.CavmdError):
+        ws.bussi_step_device(0, dvel.data_ptr() + 8, None, n, 3.0, 0.02, 3e-4, 0.5, 0.3, 0.0)
