@@ -89,6 +89,8 @@ def build(force: bool = False) -> str:
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", CSRC_DIR, "-s", "libcavmd.so"] + (["-B"] if force else []), check=True)
+    # the same library with the test hooks compiled in (fault injection; loaded by tests only, see load_hooks_build)
+    subprocess.run(["make", "-C", CSRC_DIR, "-s", "libcavmd_hooks.so"], check=True)
     # the pybind11 flavour of the shim (cavitymd._cavitymd); make rebuilds it only when stale
     subprocess.run(["make", "-C", CSRC_DIR, "-s", "pymod"], check=True)
     return LIB_PATH
@@ -104,7 +106,28 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` (or `python -c 'import __graft_entry__ as g; "
                 "g.build()'`).  The cavity force has no CPU/PyTorch fallback in this package.")
-        lib = ctypes.CDLL(LIB_PATH)
+        _lib = _declare(ctypes.CDLL(LIB_PATH))
+        return _lib
+
+
+_hooks_lib = None
+HOOKS_LIB_PATH = os.path.join(CSRC_DIR, "libcavmd_hooks.so")
+
+
+def load_hooks_build():
+    """TESTS ONLY: libcavmd_hooks.so, the same sources compiled with -DCAVMD_TEST_HOOKS (fault-injecting instantiations of the
+    single-launch kernel and the debug_* tunables that drive them).  The product library has neither."""
+    global _hooks_lib
+    with _lock:
+        if _hooks_lib is None:
+            if not os.path.exists(HOOKS_LIB_PATH):
+                raise ImportError(f"{HOOKS_LIB_PATH} is missing: build it with `make -C {CSRC_DIR} hooks`")
+            _hooks_lib = _declare(ctypes.CDLL(HOOKS_LIB_PATH))
+        return _hooks_lib
+
+
+def _declare(lib):
+    if True:
         vp, sz, dbl, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int
         P = ctypes.POINTER
         lib.cavmd_make_params.argtypes = [dbl, dbl, dbl]
@@ -164,7 +187,6 @@ def load():
         lib.cavmd_error_string.restype = ctypes.c_char_p
         lib.cavmd_version.argtypes = []
         lib.cavmd_version.restype = ci
-        _lib = lib
         return lib
 
 
@@ -200,8 +222,8 @@ def make_params(omegac: float, couplstr: float, phmass: float = 1.0) -> Params:
 class Workspace:
     """Owns one cavmd_workspace (scratch for partial sums + the 192-byte result block)."""
 
-    def __init__(self, max_N: int, device: int = -1):
-        self._lib = load()
+    def __init__(self, max_N: int, device: int = -1, hooks: bool = False):
+        self._lib = load_hooks_build() if hooks else load()
         self._h = ctypes.c_void_p()
         check(self._lib.cavmd_create(int(device), int(max_N), ctypes.byref(self._h)), "cavmd_create")
         self.max_N = int(max_N)

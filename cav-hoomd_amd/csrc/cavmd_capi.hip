@@ -93,6 +93,11 @@ struct cavmd_workspace
     int debug_spin_limit = 0;     // tests: poll rounds of the single-launch kernel's bounded waits (0 = kSpinLimit)
     int debug_late_block = -1;    // tests: this block of the single-launch grid starts debug_late_ticks late (-1 = none)
     int debug_late_ticks = 0;     //        (100 MHz wall clock)
+    int debug_silent_block = -1;  // tests: this block never publishes its record: the evaluation cannot be completed (-1 = none)
+    int debug_skip_publish = 0;   // tests: the kernels publish into a scratch block instead of the one the host reads -- what a
+                                  //        launch that failed on the device looks like from the host
+    HostResult* h_scratch = nullptr; // (hooks build only) that scratch block, pinned + mapped
+    HostResult* h_scratch_dev = nullptr;
     // after a starved evaluation the single launch is suspended: until sequence reaches suspend_until, then one probe; every
     // further starvation multiplies the pause by 8 (2^16 evaluations at first, 2^31 at most); a FAILED one suspends for good
     uint64_t suspend_until = 0;
@@ -305,13 +310,15 @@ hipError_t allow_large_lds()
         CAVMD_ALLOW(2, 1)
         CAVMD_ALLOW(2, 2)
 #undef CAVMD_ALLOW
-        // the fault-injection instantiations (tests: "debug_late_block")
+#ifdef CAVMD_TEST_HOOKS
+        // the fault-injection instantiations (tests: "debug_late_block", "debug_silent_block"; libcavmd_hooks.so only)
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, 1, 0, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cavity_persistent_kernel<kPersistBlock, 2, 0, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
+#endif
         return e;
     }();
     return once;
@@ -435,10 +442,10 @@ int cavmd_create(int device, size_t max_N, cavmd_workspace** out_ws)
     if (e == hipSuccess) // tag 0 = never valid
         e = hipMemset(ws->d_granules, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid);
     if (e == hipSuccess)
-        e = hipMalloc((void**)&ws->d_epoch, 2 * sizeof(unsigned));
+        e = hipMalloc((void**)&ws->d_epoch, 4 * sizeof(unsigned));
     if (e == hipSuccess)
     {
-        const unsigned init[2] = {1u, 0u}; // first tag; no block has given up
+        const unsigned init[4] = {1u, 0u, 0u, 0u}; // first tag; no block has given up; not poisoned
         e = hipMemcpy(ws->d_epoch, init, sizeof(init), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess)
@@ -494,6 +501,8 @@ int cavmd_destroy(cavmd_workspace* ws)
         (void)hipHostFree(ws->h_fm);
     if (ws->d_fm_ticket)
         (void)hipFree(ws->d_fm_ticket);
+    if (ws->h_scratch)
+        (void)hipHostFree(ws->h_scratch);
     if (ws->d_bussi)
         (void)hipFree(ws->d_bussi);
     if (ws->h_bussi)
@@ -509,6 +518,17 @@ namespace
 // bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- suspends the
 // single-launch path for this workspace: what starved the grid is a property of how the GPU is shared at the moment, not of
 // one step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
+// Where the kernels publish the result block for the host: the workspace's mapped block -- or, in the test-hooks build with
+// "debug_skip_publish" set, a scratch block the host never looks at (what a launch that died on the device looks like).
+inline HostResult* host_block(cavmd_workspace* ws)
+{
+#ifdef CAVMD_TEST_HOOKS
+    if (ws->debug_skip_publish && ws->h_scratch_dev)
+        return ws->h_scratch_dev;
+#endif
+    return ws->h_result_dev;
+}
+
 unsigned consume_sync_timeout(cavmd_workspace* ws)
 {
     if (!ws->h_result || !__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
@@ -581,7 +601,7 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
     {
         ws->sequence += 1;
         st = ls.launch(0, cavity_small_system_kernel<kSmallBlock>, 1u, kSmallBlock, in, n, Lx, Ly, Lz, dp, L_typeid,
-                       ws->sequence, ws->d_result, ws->h_result_dev, reinterpret_cast<v2d*>(d_force));
+                       ws->sequence, ws->d_result, host_block(ws), reinterpret_cast<v2d*>(d_force));
         if (st != CAVMD_OK)
             return st;
         ls.commit();
@@ -642,29 +662,33 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
             {
                 // re-enabled after a starved evaluation: records or give-up counts of that launch must not meet this one
                 CAVMD_HIP_TRY(hipMemsetAsync(ws->d_granules, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid, stream));
-                CAVMD_HIP_TRY(hipMemsetAsync(ws->d_epoch + 1, 0, sizeof(unsigned), stream));
+                CAVMD_HIP_TRY(hipMemsetAsync(ws->d_epoch + 1, 0, 2 * sizeof(unsigned), stream)); // give-up count and poison
                 ws->sync_state_dirty = false;
             }
             ws->sequence += 1;
             const AosInputT<2> inx {in.pos2, in.charge, in.image};
             const SyncState sync {ws->d_granules, ws->d_epoch, ws->debug_spin_limit > 0 ? (unsigned)ws->debug_spin_limit : kSpinLimit,
-                                  ws->debug_late_block, (unsigned)ws->debug_late_ticks};
+                                  ws->debug_late_block, (unsigned)ws->debug_late_ticks, ws->debug_silent_block};
 #define CAVMD_LAUNCH_PERSIST(UNR, NTS)                                                                               \
     st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, UNR, NTS>, g1, kPersistBlock, inx, n, Lx, Ly, Lz, \
-                       dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2, (unsigned)lds_slots, balanced);
-            if (ws->debug_late_block >= 0)
+                       dp, L_typeid, sync, ws->sequence, ws->d_result, host_block(ws), force2, (unsigned)lds_slots, balanced);
+#ifdef CAVMD_TEST_HOOKS
+            if (ws->debug_late_block >= 0 || ws->debug_silent_block >= 0)
             {
-                // fault injection (tests): one block starts late -> the grid starves itself and has to be repaired
+                // fault injection (tests): one block starts late -> the grid starves itself and has to be repaired; or one block
+                // never publishes -> the evaluation cannot be completed
                 if (unroll == 2)
                     st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, 2, 0, true>, g1, kPersistBlock, inx, n, Lx, Ly,
-                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2,
+                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, host_block(ws), force2,
                                        (unsigned)lds_slots, balanced);
                 else
                     st = ls.launch_lds(0, lds, cavity_persistent_kernel<kPersistBlock, 1, 0, true>, g1, kPersistBlock, inx, n, Lx, Ly,
-                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, ws->h_result_dev, force2,
+                                       Lz, dp, L_typeid, sync, ws->sequence, ws->d_result, host_block(ws), force2,
                                        (unsigned)lds_slots, balanced);
             }
-            else if (unroll == 2)
+            else
+#endif
+            if (unroll == 2)
             {
                 if (nt_store == 2)
                     CAVMD_LAUNCH_PERSIST(2, 2)
@@ -733,19 +757,19 @@ int cavmd_compute_hoomd(cavmd_workspace* ws, void* stream_, size_t N, const cavm
         // ---- launch 2 of 2: every force-map block folds the partials itself, block 0 publishes the result block
         if (nt_store == 2)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 2>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, host_block(ws), force2, map_reverse);
         else if (nt_store == 1)
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 1>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, host_block(ws), force2, map_reverse);
         else
             st = ls.launch(2, force_map_aos_fused_kernel<kMapBlock, kMapUnroll, 0>, g2, kMapBlock, in, n, g1, Lx, Ly,
-                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, ws->h_result_dev, force2, map_reverse);
+                           Lz, dp, L_typeid, part, ws->sequence, ws->d_result, host_block(ws), force2, map_reverse);
     }
     else
     {
         // ---- three-launch variant (kept for A/B): finalize, then a force map that reads the result block
         st = ls.launch(1, finalize_kernel<AosInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
-                       part, ws->sequence, ws->d_result, ws->h_result_dev);
+                       part, ws->sequence, ws->d_result, host_block(ws));
         if (st != CAVMD_OK)
             return st;
         const cavmd_result* res = ws->d_result;
@@ -849,12 +873,12 @@ int cavmd_compute_soa(cavmd_workspace* ws, void* stream_, size_t N, const double
     if (ws->fused_finalize)
     {
         st = ls.launch(2, force_map_strided_fused_kernel<kMapBlock>, g2, kMapBlock, in, n, g1, Lx, Ly, Lz, dp, L_typeid, part,
-                       ws->sequence, ws->d_result, ws->h_result_dev, f_out, force_stride, pe_out, potential_energy_stride);
+                       ws->sequence, ws->d_result, host_block(ws), f_out, force_stride, pe_out, potential_energy_stride);
     }
     else
     {
         st = ls.launch(1, finalize_kernel<StridedInput, kFinalizeBlock>, 1u, kFinalizeBlock, in, n, g1, Lx, Ly, Lz, dp,
-                       part, ws->sequence, ws->d_result, ws->h_result_dev);
+                       part, ws->sequence, ws->d_result, host_block(ws));
         if (st != CAVMD_OK)
             return st;
         const cavmd_result* res = ws->d_result;
@@ -877,6 +901,7 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
     if (!ws->computed)
         return CAVMD_ERR_NOT_COMPUTED;
     DeviceGuard guard(ws->device);
+    bool published = true;
     if (ws->captured)
     {
         // graph replays: the flag cannot be trusted (frozen sequence) and the replay stream is unknown -> wait for the device
@@ -896,7 +921,7 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
             const hipError_t q = hipStreamQuery(ws->last_stream);
             if (q == hipSuccess)
             {
-                (void)__atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE);
+                published = __atomic_load_n(&ws->h_result->ready, __ATOMIC_ACQUIRE) == want;
                 break;
             }
             if (q != hipErrorNotReady)
@@ -908,6 +933,14 @@ int cavmd_result_read(cavmd_workspace* ws, cavmd_result* out)
     // One that its last block completed has published its result like any other.
     if (consume_sync_timeout(ws) == kSyncFailed)
         return CAVMD_ERR_SYNC_TIMEOUT;
+    if (!published)
+    {
+        // the stream is idle and the flag does not carry this evaluation's sequence: its launch failed on the device.  The
+        // block in host memory belongs to an EARLIER evaluation: not handed out, and invalidated (as wait_scalar does for the
+        // scalar reductions)
+        ws->computed = false;
+        return (int)hipErrorLaunchFailure;
+    }
     memcpy(out, &ws->h_result->result, sizeof(cavmd_result));
     return CAVMD_OK;
 }
@@ -1043,6 +1076,10 @@ int cavmd_cavity_mode(cavmd_workspace* ws, void* stream_, const cavmd_double4* d
         return CAVMD_ERR_INVALID_VALUE;
     if (!ws->computed)
         return CAVMD_ERR_NOT_COMPUTED;
+    // the photon index and E_h are read from the last evaluation's device-side result: if that evaluation was starved and
+    // could not be completed, the block on the device still belongs to the evaluation BEFORE it -> say so instead
+    if (consume_sync_timeout(ws) == kSyncFailed)
+        return CAVMD_ERR_SYNC_TIMEOUT;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
     if (!ws->d_mode)
@@ -1443,6 +1480,7 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->suspend_backoff = kSuspendFirst;
         return CAVMD_OK;
     }
+#ifdef CAVMD_TEST_HOOKS
     if (!strcmp(name, "debug_suspend_first"))
     {
         if (value < 1)
@@ -1471,17 +1509,44 @@ int cavmd_set_tunable(cavmd_workspace* ws, const char* name, int value)
         ws->debug_late_ticks = value;
         return CAVMD_OK;
     }
+    if (!strcmp(name, "debug_silent_block"))
+    {
+        if (value < -1 || value >= (int)kMaxPersistGrid)
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->debug_silent_block = value;
+        return CAVMD_OK;
+    }
+    if (!strcmp(name, "debug_skip_publish"))
+    {
+        if (value < 0 || value > 1)
+            return CAVMD_ERR_INVALID_VALUE;
+        if (value && !ws->h_scratch)
+        {
+            DeviceGuard guard(ws->device);
+            CAVMD_HIP_TRY(hipHostMalloc((void**)&ws->h_scratch, sizeof(HostResult), hipHostMallocMapped | hipHostMallocCoherent));
+            memset(ws->h_scratch, 0, sizeof(HostResult));
+            CAVMD_HIP_TRY(hipHostGetDevicePointer((void**)&ws->h_scratch_dev, ws->h_scratch, 0));
+        }
+        ws->debug_skip_publish = value;
+        return CAVMD_OK;
+    }
+#endif
     if (!strcmp(name, "sync_timeout_seen"))
     {
-        // fault-injection hook: raises the flag of the host-visible block as a starved single-launch kernel would -- 1: the
-        // evaluation failed, 2: its last block completed it -- so that callers and tests can exercise their handling; 0 forgets
-        // a time-out seen earlier
+        // 0 forgets a time-out seen earlier.  In the test-hooks build also a fault-injection hook: raises the flag of the
+        // host-visible block as a starved single-launch kernel would -- 1: the evaluation failed, 2: its last block completed it
+#ifdef CAVMD_TEST_HOOKS
         if (value < 0 || value > 2)
             return CAVMD_ERR_INVALID_VALUE;
         if (value)
             __atomic_store_n(&ws->h_result->sync_error, value == 2 ? kSyncRepaired : kSyncFailed, __ATOMIC_RELEASE);
         else
             ws->sync_timeout_seen = false;
+#else
+        if (value != 0) // raising the flag is a fault-injection hook: libcavmd_hooks.so only
+            return CAVMD_ERR_INVALID_VALUE;
+        ws->sync_timeout_seen = false;
+#endif
         return CAVMD_OK;
     }
     if (!strcmp(name, "reduce_unroll"))
@@ -1539,12 +1604,23 @@ int cavmd_get_tunable(cavmd_workspace* ws, const char* name, int* value)
         *value = ws->sync_timeout_seen ? 1 : 0;
     else if (!strcmp(name, "persistent_suspended"))
         *value = ws->suspend_until == kSuspendForever ? 2 : (ws->sequence < ws->suspend_until ? 1 : 0);
+#ifdef CAVMD_TEST_HOOKS
     else if (!strcmp(name, "debug_spin_limit"))
         *value = ws->debug_spin_limit;
     else if (!strcmp(name, "debug_late_block"))
         *value = ws->debug_late_block;
     else if (!strcmp(name, "debug_late_ticks"))
         *value = ws->debug_late_ticks;
+    else if (!strcmp(name, "debug_silent_block"))
+        *value = ws->debug_silent_block;
+    else if (!strcmp(name, "debug_skip_publish"))
+        *value = ws->debug_skip_publish;
+    else if (!strcmp(name, "test_hooks"))
+        *value = 1;
+#else
+    else if (!strcmp(name, "test_hooks"))
+        *value = 0;
+#endif
     else if (!strcmp(name, "reduce_unroll"))
         *value = ws->reduce_unroll;
     else if (!strcmp(name, "rho_lane_particle"))

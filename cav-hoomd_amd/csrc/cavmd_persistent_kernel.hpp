@@ -30,6 +30,11 @@
 // bounded; a block that gives up poisons its tiles with NaN, is counted and LEAVES, which lets the missing blocks start; they
 // give up in turn (the count rides along with their polls), and the last one, which knows from the count that every record
 // is in place, folds them in the same order and writes every tile itself -- late, but the same bits (bail path below).
+// An evaluation whose blocks were not ALL counted on the bail path (some had completed before the first give-up) leaves
+// epoch[2] (the poison word) set to its launch nonce: every block of every LATER launch reads it with the tag at kernel
+// entry and fails at once and as a whole (NaN forces, kSyncFailed), without touching the records or the give-up count of
+// the failed launch -- so launches already queued behind a failure, or replays of a captured graph, end
+// loudly whatever the slabs and counters were left like; only the host clears the word (cavmd_capi.hip, sync_state_dirty).
 #pragma once
 
 #include "cavmd_force_kernels.hpp"
@@ -59,10 +64,14 @@ struct SyncState
     unsigned long long* granules; // kMaxPersistGrid block records, then kGroupCopies x kGroup group records; a record is
                                   // kGranulesPerRecord granules {tag << 32 | value} = 160 contiguous bytes
     unsigned* epoch;              // epoch[0]: tag of the next evaluation (never 0); epoch[1]: blocks of the running evaluation
-                                  // that gave up waiting (0 outside a starved evaluation)
+                                  // that gave up waiting (0 outside a starved evaluation); epoch[2]: poison -- the nonce of
+                                  // the launch some block of which gave up, from its first give-up until its last block has
+                                  // put the state back in order (or for good, until the host wipes it, if nobody could)
     unsigned spin_limit;          // poll rounds of a bounded wait (kSpinLimit; tests shorten it)
     int late_block;               // fault injection (FAULT instantiation only): this block starts late_ticks of the 100 MHz
     unsigned late_ticks;          // wall clock late, as if its CU had been held by another grid; -1: none
+    int silent_block;             // fault injection (FAULT instantiation only): this block never publishes its record, as if
+                                  // it were not resident -> the evaluation cannot be completed; -1: none
 };
 // HostResult::sync_error
 constexpr unsigned kSyncFailed = 1u;   // some block gave up and nobody could complete the evaluation: its forces hold NaN
@@ -74,11 +83,16 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 }
 
 // lane 0's Accum -> the 20 words of a record in LDS (word 2 i = low half, 2 i + 1 = high half of double i)
+// (written as 32-bit words, the type they are read back as: no aliasing between double and unsigned accesses to the same LDS)
 __device__ __forceinline__ void record_to_lds(unsigned* s_rec, const Accum& a)
 {
-    double* sd = reinterpret_cast<double*>(s_rec);
-    sd[0] = a.hx; sd[1] = a.lx; sd[2] = a.hy; sd[3] = a.ly; sd[4] = a.hz; sd[5] = a.lz;
-    sd[6] = a.sx; sd[7] = a.sy; sd[8] = a.sz;
+    const double d[kNumPartDoubles] = {a.hx, a.lx, a.hy, a.ly, a.hz, a.lz, a.sx, a.sy, a.sz};
+#pragma unroll
+    for (int i = 0; i < kNumPartDoubles; ++i)
+    {
+        s_rec[2 * i] = (unsigned)__double2loint(d[i]);
+        s_rec[2 * i + 1] = (unsigned)__double2hiint(d[i]);
+    }
     s_rec[2 * kNumPartDoubles] = (unsigned)a.lmin;
     s_rec[2 * kNumPartDoubles + 1] = (unsigned)a.lcnt;
 }
@@ -259,6 +273,16 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     }
     // this evaluation's tag, and the speculative photon row (the driver appends the photon last)
     const unsigned tag = __hip_atomic_load(st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The poison word holds the NONCE of the launch whose blocks raised it.  A nonce of another launch = an earlier evaluation
+    // that nobody could complete: this launch fails as a whole (see the end of the kernel).  This launch's own nonce = blocks of
+    // this very grid have given up while this one could not start: the bail path below, not a failure yet.
+    // The nonce: address of the launch's AQL dispatch packet (grid-uniform, an SGPR pair; consecutive dispatches of a queue --
+    // replays of a captured graph included -- occupy different slots of its ring: 128 or 256 bytes apart on gfx950 / ROCm 7.2,
+    // scripts/dev/dispatch_id_probe.hip) mixed with the host's sequence number; never 0.
+    const unsigned nonce = ((unsigned)((uintptr_t)__builtin_amdgcn_dispatch_ptr() >> 6) * 2654435761u
+                            ^ (unsigned)sequence * 40503u) | 1u;
+    const unsigned poison = __hip_atomic_load(st.epoch + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool poisoned = poison != 0u && poison != nonce;
     const PhotonRow guess = photon_row(in, (size_t)(N - 1));
 
     // ---- phase 1: partial dipole of this block's tiles; the charges of its first lds_slots tiles are parked in LDS ---------
@@ -334,13 +358,21 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
     }
     if (tid < kWave)
     {
-        bool ok = true;
+        bool ok = !poisoned;
+        bool silent = false;
 #ifdef CAVMD_FAULT_SILENT_BLOCK // microbench only: this block never publishes, as if it were not resident
-        if (b != CAVMD_FAULT_SILENT_BLOCK)
+        silent = (b == CAVMD_FAULT_SILENT_BLOCK);
 #endif
-        publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc, s_words);
+        if constexpr (FAULT)
+            silent = silent || ((int)b == st.silent_block);
+        if (!silent && !poisoned)
+            publish_record(block_slab, kMaxPersistGrid, 1, b, tag, acc, s_words);
         Accum o, t;
-        if (G <= (unsigned)kGroup)
+        if (poisoned)
+        {
+            // nothing is published, gathered or counted
+        }
+        else if (G <= (unsigned)kGroup)
         {
             // A grid of at most 16 blocks (N up to ~4000) is ONE group: every block gathers the block records itself, its own
             // from registers -- one hop instead of two, and the same fold (the second level would only add zeros).
@@ -455,7 +487,15 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
         if (tid == 0)
         {
             __hip_atomic_store(&res_host->sync_error, kSyncFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s_last = __hip_atomic_fetch_add(st.epoch + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+            if (poisoned)
+                s_last = 0u; // a launch behind an evaluation nobody could complete: fail as a whole, touch nothing
+            else
+            {
+                // poison first (the counting atomic below orders it): it stays unless ALL blocks end up counted here, i.e.
+                // unless the last of them can put records, count and epoch back in order
+                __hip_atomic_store(st.epoch + 2, nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = __hip_atomic_fetch_add(st.epoch + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+            }
         }
         __syncthreads();
         if (!s_last)
@@ -512,9 +552,11 @@ __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> i
             slow_map(0, 1, false, mr); // over the other blocks' NaN: their stores were fenced before they were counted
         if (tid == 0)
         {
-            // every block has read the epoch and been counted: leave both ready for the next evaluation
+            // every block has read the epoch and been counted, none is left in the hand-off: count, epoch and poison are put
+            // back in order for the next evaluation (whether or not THIS one could be completed: that is sync_error's to say)
             __hip_atomic_store(st.epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st.epoch, tag + 1u ? tag + 1u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.epoch + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }

@@ -91,11 +91,11 @@ int main(int argc, char** argv)
     CHECK(hipMalloc((void**)&d_hres, sizeof(HostResult)));
     CHECK(hipMalloc((void**)&d_gran, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
     CHECK(hipMemset(d_gran, 0, sizeof(unsigned long long) * 2 * kGranulesPerRecord * kMaxPersistGrid));
-    CHECK(hipMalloc((void**)&d_epoch, 8));
-    const unsigned epoch_init[2] = {1u, 0u};
-    CHECK(hipMemcpy(d_epoch, epoch_init, 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc((void**)&d_epoch, 16));
+    const unsigned epoch_init[4] = {1u, 0u, 0u, 0u};
+    CHECK(hipMemcpy(d_epoch, epoch_init, 16, hipMemcpyHostToDevice));
     Partials part {d_part, d_ipart, max_parts};
-    SyncState sync {d_gran, d_epoch, kSpinLimit, -1, 0u};
+    SyncState sync {d_gran, d_epoch, kSpinLimit, -1, 0u, -1};
     const double L = 215.4;
     const unsigned n = (unsigned)N;
     hipStream_t st = 0;
@@ -167,7 +167,7 @@ int main(int argc, char** argv)
         float ms; CHECK(hipEventElapsedTime(&ms, a, b2));
         HostResult hr; CHECK(hipMemcpy(&hr, d_hres, sizeof(hr), hipMemcpyDeviceToHost));
         cavmd_result got_res; CHECK(hipMemcpy(&got_res, d_res, sizeof(got_res), hipMemcpyDeviceToHost));
-        unsigned after[2]; CHECK(hipMemcpy(after, d_epoch, 8, hipMemcpyDeviceToHost));
+        unsigned after[3]; CHECK(hipMemcpy(after, d_epoch, 12, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(h_f.data(), d_frc[0], 32 * N, hipMemcpyDeviceToHost));
         size_t nan = 0, differ = 0;
         for (size_t i = 0; i < h_f.size(); ++i) { nan += (h_f[i] != h_f[i]); differ += memcmp(&h_f[i], &h_want[i], 8) != 0; }
@@ -175,16 +175,16 @@ int main(int argc, char** argv)
                                  && memcmp(hr.result.dipole, want_res.dipole, sizeof(got_res.dipole)) == 0;
 #ifdef CAVMD_FAULT_SILENT_BLOCK
         (void)differ; (void)same_dipole;
-        printf("fault injection (block %d silent, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu of %zu, epoch %u, give-up count left %u\n",
-               CAVMD_FAULT_SILENT_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, h_f.size(), after[0], after[1]);
+        printf("fault injection (block %d silent, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu of %zu, epoch %u, give-up count left %u, poison word %s\n",
+               CAVMD_FAULT_SILENT_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, h_f.size(), after[0], after[1], after[2] ? "set" : "clear");
         // (with at most 16 blocks every block gathers the block records itself: the silent block, which has its own record in
         // registers, completes its own tile and leaves; the others can never be complete -- a stuck give-up count and an epoch
         // that was not advanced are what the host wipes before it would use the single launch again)
         return (hr.sync_error == 1 && nan >= h_f.size() - 4 * (size_t)tile && hr.ready == 0) ? 0 : 1;
 #else
-        printf("fault injection (block %d late, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu, force entries differing from the two-launch path %zu of %zu, dipole identical %d, epoch %u, give-up count left %u\n",
-               CAVMD_FAULT_LATE_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, differ, h_f.size(), (int)same_dipole, after[0], after[1]);
-        return (hr.sync_error == 2 && nan == 0 && differ == 0 && hr.ready == 7 && same_dipole && after[0] == 2 && after[1] == 0) ? 0 : 1;
+        printf("fault injection (block %d late, grid %u): kernel returned after %.1f ms, sync_error=%u, ready=%llu, NaN force entries %zu, force entries differing from the two-launch path %zu of %zu, dipole identical %d, epoch %u, give-up count left %u, poison word %s\n",
+               CAVMD_FAULT_LATE_BLOCK, g1, ms, hr.sync_error, (unsigned long long)hr.ready, nan, differ, h_f.size(), (int)same_dipole, after[0], after[1], after[2] ? "set" : "clear");
+        return (hr.sync_error == 2 && nan == 0 && differ == 0 && hr.ready == 7 && same_dipole && after[0] == 2 && after[1] == 0 && after[2] == 0) ? 0 : 1;
 #endif
     }
 #endif

@@ -138,3 +138,43 @@ def test_header_is_plain_c_and_links(capi, tmp_path):
     assert out.returncode == 0 and "C-ABI-OK" in out.stdout, (out.returncode, out.stdout, out.stderr[-2000:])
     if not torch.cuda.is_available():
         assert "refused with CAVMD_ERR_NO_DEVICE" in out.stdout
+
+
+def test_the_product_library_carries_no_test_hooks(capi):
+    """The fault-injecting instantiations of the single-launch kernel (FAULT = true) and the debug_* tunables that drive them
+    exist in libcavmd_hooks.so only (`make hooks`, -DCAVMD_TEST_HOOKS); the library a caller links has neither, so no caller
+    can make a production workspace stall."""
+    import subprocess
+    from cavitymd import _capi
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    fault = "cavity_persistent_kernelILi256ELi2ELi0ELb1E"       # <256, 2, 0, FAULT = true, ...>
+
+    def kernel_names(path):
+        # the device symbols sit in the embedded code object; their names also appear in the host binary's string table
+        with open(path, "rb") as f:
+            return f.read()
+
+    assert fault.encode() not in kernel_names(_capi.LIB_PATH)
+    assert fault.encode() in kernel_names(_capi.HOOKS_LIB_PATH)
+    for name in (b"debug_late_block", b"debug_spin_limit", b"debug_late_ticks", b"debug_suspend_first", b"debug_silent_block",
+                 b"debug_skip_publish"):
+        assert name not in kernel_names(_capi.LIB_PATH), name
+        assert name in kernel_names(_capi.HOOKS_LIB_PATH), name
+    assert os.path.exists(nm) or True
+
+
+@pytest.mark.gpu
+def test_the_product_library_rejects_the_hook_tunables():
+    from cavitymd import _capi
+    ws = _capi.Workspace(1000)
+    assert ws.get_tunable("test_hooks") == 0
+    for name, value in (("debug_late_block", 3), ("debug_spin_limit", 5000), ("debug_late_ticks", 1000), ("debug_suspend_first", 4),
+                        ("debug_silent_block", 1), ("debug_skip_publish", 1), ("sync_timeout_seen", 1), ("sync_timeout_seen", 2)):
+        with pytest.raises(_capi.CavmdError) as e:
+            ws.set_tunable(name, value)
+        assert e.value.status == _capi.CAVMD_ERR_INVALID_VALUE, name
+    ws.set_tunable("sync_timeout_seen", 0)          # forgetting a time-out seen earlier is the caller's to do: stays
+    hooks = _capi.Workspace(1000, hooks=True)
+    assert hooks.get_tunable("test_hooks") == 1
+    hooks.set_tunable("debug_late_block", 3)
+    assert hooks.get_tunable("debug_late_block") == 3

@@ -14,6 +14,7 @@ import ctypes
 import json
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -778,7 +779,8 @@ def test_a_sync_timeout_is_reported_once_and_the_workspace_falls_back_to_two_lau
     img = torch.from_numpy(cfg["image"]).to(dev)
     prm = _capi.make_params(0.0091, 1e-3, 1.0)
     L = cfg["box"]
-    ws = _capi.Workspace(n)
+    ws = _capi.Workspace(n, hooks=True)              # libcavmd_hooks.so: the product library cannot raise the flag by hand
+    assert ws.get_tunable("test_hooks") == 1
     assert ws.get_tunable("persistent") == -1 and ws.get_tunable("sync_timeout_seen") == 0
     frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
     ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc.data_ptr())
@@ -833,7 +835,7 @@ def test_a_starved_evaluation_is_completed_by_its_last_block(n):
     want_f = frc.clone()
     grid = want.n_partials                      # the single-launch grid is the two-launch path's reduction grid
     for late in sorted({0, min(5, grid - 1), grid - 1}):
-        ws = _capi.Workspace(n)
+        ws = _capi.Workspace(n, hooks=True)
         ws.set_tunable("persistent", 1)
         ws.set_tunable("debug_spin_limit", 5000)
         ws.set_tunable("debug_late_block", late)
@@ -869,7 +871,7 @@ def test_a_suspended_single_launch_is_probed_again_with_back_off():
     prm = _capi.make_params(0.0091, 1e-3, 1.0)
     L = cfg["box"]
     frc = torch.empty((n, 4), dtype=torch.float64, device=dev)
-    ws = _capi.Workspace(n)
+    ws = _capi.Workspace(n, hooks=True)
     ws.set_tunable("persistent", 1)
     ws.profile_enable(True)
 
@@ -944,3 +946,85 @@ def test_graph_replays_on_changing_data_read_without_sync(ref, oracle_mod):
             gpu = {"force": comp.getForceArray().cpu().numpy(), "energies": e, "dipole": np.array(res.dipole[:]),
                    "photon_idx": res.photon_idx}
             check_parity(cur, gpu, ref_eval(ref, oracle_mod, cur))
+
+
+def _device_inputs(n, seed, photon_at):
+    cfg = _random_cfg(n, seed=seed, photon_at=photon_at)
+    dev = "cuda"
+    pos = torch.from_numpy(np.concatenate([cfg["position"], cavitymd.state.type_tag_as_double(cfg["typeid"])[:, None]], axis=1)).to(dev)
+    return cfg, pos, torch.from_numpy(cfg["charge"]).to(dev), torch.from_numpy(cfg["image"]).to(dev)
+
+
+def test_result_read_reports_an_evaluation_that_never_published():
+    """The stream has drained and the host-visible flag does not carry the evaluation's sequence: its launch failed on the
+    device.  cavmd_result_read must say so (hipErrorLaunchFailure, as the scalar reductions' wait does) and invalidate the
+    block -- NOT hand out the previous evaluation's numbers with CAVMD_OK.  Provoked through the hooks build: the kernels
+    publish into a scratch block the host never reads.  All three launch shapes."""
+    for n, tun in ((501, {}), (60_001, {}), (60_001, {"persistent": 0})):
+        cfg, pos, chg, img = _device_inputs(n, seed=n, photon_at=n - 1)
+        prm = _capi.make_params(0.0091, 1e-3, 1.0)
+        frc = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+        ws = _capi.Workspace(n, hooks=True)
+        for k, v in tun.items():
+            ws.set_tunable(k, v)
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), cfg["box"], 2, prm, frc.data_ptr())
+        first = np.array(ws.result().dipole[:])
+        ws.set_tunable("debug_skip_publish", 1)
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), cfg["box"], 2, prm, frc.data_ptr())
+        with pytest.raises(_capi.CavmdError) as e:
+            ws.result()
+        assert e.value.status > 0                                   # a hipError_t, not a CAVMD_ERR_* code
+        with pytest.raises(_capi.CavmdError) as e:
+            ws.result()                                             # and the stale block is not handed out afterwards either
+        assert e.value.status == _capi.CAVMD_ERR_NOT_COMPUTED
+        assert ws.energies() == (0.0, 0.0, 0.0) or list(ws.energies()) == [0.0, 0.0, 0.0]
+        ws.set_tunable("debug_skip_publish", 0)
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), cfg["box"], 2, prm, frc.data_ptr())
+        assert np.array_equal(np.array(ws.result().dipole[:]), first)
+
+
+@pytest.mark.parametrize("n", [3_001, 60_001])
+def test_launches_queued_behind_an_evaluation_nobody_could_complete_fail_as_a_whole(n):
+    """a starved evaluation that ends UNREPAIRED used to leave the in-kernel hand-off state dirty (stuck
+    give-up count, epoch not advanced) with only the host to clean it -- launches already queued behind it ran on that state
+    and could end with a result flagged valid.  Now the failing evaluation leaves a poison word that every block of every
+    later launch reads at entry: those launches fail at once and as a whole.  Provoked for real: one block of the grid never
+    publishes its record (hooks build), spin limit cut; then TWO more evaluations are enqueued with no host call in between
+    that could notice anything (the host flag is raised only when the first kernel's waits run out, milliseconds later).
+    n = 3001: a one-hop grid (the silent block completes on its own, the count can never reach G: the advisor's case);
+    n = 60001: two levels."""
+    cfg, pos, chg, img = _device_inputs(n, seed=n + 7, photon_at=n // 2)
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    L = cfg["box"]
+    frc = [torch.full((n, 4), 7.0, dtype=torch.float64, device="cuda") for _ in range(3)]
+    ref_ws = _capi.Workspace(n)
+    want = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+    ref_ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, want.data_ptr())
+    want_d = np.array(ref_ws.result().dipole[:])
+    ws = _capi.Workspace(n, hooks=True)
+    ws.set_tunable("persistent", 1)
+    ws.set_tunable("small_system_max_n", 0)
+    ws.set_tunable("debug_spin_limit", 5000)
+    ws.set_tunable("debug_silent_block", 1)
+    t0 = time.perf_counter()
+    for k in range(3):                                   # all three enqueued back to back, asynchronously
+        ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc[k].data_ptr())
+    assert time.perf_counter() - t0 < 0.5
+    ws.set_tunable("debug_silent_block", -1)
+    with pytest.raises(_capi.CavmdError) as e:
+        ws.result()
+    assert e.value.status == _capi.CAVMD_ERR_SYNC_TIMEOUT
+    torch.cuda.synchronize()
+    # evaluation 1: the blocks that gave up poisoned their tiles; 2 and 3 ran behind it on the poisoned state: NaN everywhere
+    assert bool(torch.isnan(frc[0]).any())
+    assert bool(torch.isnan(frc[1]).all()) and bool(torch.isnan(frc[2]).all())
+    with pytest.raises(_capi.CavmdError) as e:
+        ws.result()                                      # nothing of this is ever handed out as a result
+    assert e.value.status == _capi.CAVMD_ERR_NOT_COMPUTED
+    assert ws.get_tunable("persistent_suspended") == 2
+    # the caller switches the single launch on again: the host wipes slabs, count and poison before it runs; same bits as ever
+    ws.set_tunable("persistent", 1)
+    ws.compute_hoomd(0, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), L, 2, prm, frc[0].data_ptr())
+    assert np.array_equal(np.array(ws.result().dipole[:]), want_d)
+    torch.cuda.synchronize()
+    assert torch.equal(frc[0].view(torch.int64), want.view(torch.int64))
