@@ -1,9 +1,12 @@
-// CavityForceComputeHIP.cc -- see the header.  UNBUILT in this repository's image (no HOOMD-blue headers).
+// CavityForceComputeHIP.cc -- see the header.  Never built against HOOMD-blue in this repository's image (it has no HOOMD-blue
+// headers); compiled and run there only against the STAND-IN declarations of tests/stubs/hoomd_cpp (tests/test_hoomd_cpp_shim.py:
+// handle scopes, energy cache, N = 0, workspace growth), which says nothing about a real HOOMD-blue.
 //
 // What the reference's GPU class does per step and this one does not (src/CavityForceComputeGPU.cc:129-226):
 // four hipMemsets, one H2D and two blocking D2H copies, hipDeviceSynchronize, a host ArrayHandle on the force AND
 // position arrays (a full device->host migration under GlobalArray) and an O(N) host scan.  Here: acquire four
-// device handles, enqueue one kernel (two above ~5e6 particles) on the null stream (HOOMD-blue's stream), release.
+// device handles, enqueue one kernel (two above ~2.4e6 particles, one single-block kernel up to 1024) on the null stream
+// (HOOMD-blue's stream), release.
 // Energies are fetched lazily, once per EVALUATION, when a getter is called (EnergyTracker polls them every step).
 #include "CavityForceComputeHIP.h"
 
@@ -20,6 +23,18 @@ static_assert(sizeof(int3) == sizeof(cavmd_int3), "int3 layout");
 
 static void check(int status, const char* where)
     {
+    if (status == CAVMD_ERR_SYNC_TIMEOUT)
+        {
+        // Reported by the call AFTER the evaluation it concerns: a single-launch evaluation whose workgroups were not resident
+        // together AND that its last workgroup could not complete (the rare outcome; a starved evaluation is normally completed,
+        // late but bit-identical, and reports nothing).  libcavmd itself recovers -- the workspace is on two launches from now
+        // on and the next call works -- but the forces of THAT step were NaN and HOOMD-blue has integrated them by now, so the
+        // run cannot be continued; re-enqueueing here would only hide where it went wrong.
+        throw std::runtime_error(std::string("cavitymd (HIP): ") + where
+                                 + ": the previous step's cavity-force evaluation was starved of compute units and could not be "
+                                   "completed (its forces were NaN and have been integrated); restart from the last checkpoint with "
+                                   "CAVMD_PERSISTENT=0 in the environment if the GPU is shared with other processes");
+        }
     if (status != CAVMD_OK)
         throw std::runtime_error(std::string("cavitymd (HIP): ") + where + ": " + cavmd_error_string(status));
     }

@@ -1,7 +1,9 @@
 // CavityForceComputeHIP.h -- HOOMD-blue 4.x ForceCompute whose computeForces() enqueues libcavmd's HIP kernels.
 //
 // COMPILE-GATED: built only when CMake finds HOOMD-blue (find_package(HOOMD)); the build/test image of this
-// repository has no HOOMD headers, so this file is UNBUILT and UNTESTED there.  It is the C++ half of the drop-in:
+// repository has no HOOMD headers, so this file has never met HOOMD-blue.  There it is compiled and executed against the
+// stand-in declarations of tests/stubs/hoomd_cpp only (tests/test_hoomd_cpp_shim.py), which keeps it from rotting and
+// exercises its own logic -- and proves nothing about the real API.  It is the C++ half of the drop-in:
 // it exports the same Python-visible names as the reference's _cavitymd.CavityForceComputeGPU
 // (reference: src/CavityForceComputeGPU.h:30-56, src/CavityForceComputeGPU.cc:257-264) and therefore slots into
 // the attach ladder of hoomd.cavitymd.CavityForce (reference: src/cavitymd/forces.py:97-173) as the first rung.
