@@ -365,8 +365,15 @@ def density_field_measurement(cfg, device, n_k=50, kmag=1.0, steps=20, warmup=3)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / steps
     n = pd.getN()
+    # priced against fp64 VALU issue: 34 fp64 instructions per term (5 for k.r, 27 for the reduced sincos, 2 accumulations), one
+    # wave instruction = 64 lanes in 4 cycles per SIMD -> 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-instructions/s;
+    # with 50 of 64 lanes carrying a wavevector the reachable rate is 50/64 of that
+    lane_rate = 256 * 4 * 16 * 2.4e9
     return {"N": n, "n_k": n_k, "us_per_call": 1e6 * t, "sincos_per_s": n * n_k / t,
-            "note": "fp64 transcendental bound: N*n_k sincos per call; positions are only 32 N bytes"}
+            "fp64_instruction_issue_fraction": 34.0 * n * n_k / t / lane_rate,
+            "fraction_of_reachable_with_idle_lanes": 34.0 * n * n_k / t / (lane_rate * n_k / (64.0 * math.ceil(n_k / 64))),
+            "note": "fp64 instruction-issue bound (transcendentals by polynomial): N*n_k sincos per call, 34 fp64 instructions "
+                    "each; positions are only 32 N bytes"}
 
 
 def thermostat_measurement(n, device, steps=50, warmup=5):
@@ -389,14 +396,27 @@ def thermostat_measurement(n, device, steps=50, warmup=5):
     for _ in range(steps):
         th.kinetic_energy(dvel)
     t_ke = (time.perf_counter() - t0) / steps
+    vrng = np.random.default_rng(3)
+    draws = [thermostats.draw_variates(vrng, dof) for _ in range(64)]   # varying draws: alpha != 1 in every step
     t0 = time.perf_counter()
     for s in range(steps):
-        th.step(s, 1.0, dvel, dof, variates=var)
+        th.step(s, 1.0, dvel, dof, variates=draws[s % 64])
     torch.cuda.synchronize()
     t_step = (time.perf_counter() - t0) / steps
+    for s in range(warmup):
+        th.step_async(s, 1.0, dvel, dof, variates=draws[s % 64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        th.step_async(s, 1.0, dvel, dof, variates=draws[s % 64])
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t0) / steps
     return {"N": n, "kinetic_energy_us": 1e6 * t_ke, "kinetic_energy_GBps": 32 * n / t_ke / 1e9, "full_step_us": 1e6 * t_step,
-            "note": "KE = one kernel, the number reaches the host through a mapped flag (the scalar rule needs it); a step adds the "
-                    "asynchronous rescale kernel"}
+            "full_step_on_device_us": 1e6 * t_dev, "full_step_on_device_GBps": 96 * n / t_dev / 1e9,
+            "note": "host rule: KE = one kernel, the number reaches the host through a mapped flag, host arithmetic, then the "
+                    "rescale kernel.  on device (cavmd_bussi_step_device): the KE kernel's folding block evaluates the rule, the "
+                    "rescale kernel reads alpha from device memory; back to back, no host round trip; 96 N bytes per step "
+                    "(32 N read + 64 N read/write).  Kernel times: profiles/r03/observables_kernel_stats.csv"}
 
 
 def main():

@@ -37,7 +37,12 @@
  *     cavmd_energies) behind a hipDeviceSynchronize instead of the host-visible flag: a replayed kernel
  *     carries the sequence number of its capture, so the flag cannot tell replays apart.
  *     A graph whose replay ended in CAVMD_ERR_SYNC_TIMEOUT must be captured again before it is replayed (the
- *     library's own recovery -- two launches, wiped hand-off slabs -- does not reach into a captured graph).
+ *     library's own recovery -- two launches, wiped hand-off slabs -- does not reach into a captured graph): until then
+ *     every replay of it fails at once and as a whole (NaN forces, nothing published; the poison word of
+ *     cavmd_persistent_kernel.hpp), it never yields a result.  A graph captured while the single-launch evaluation was in
+ *     use keeps that kernel also after a starved-but-REPAIRED replay (valid results): the back-off that moves a workspace
+ *     to two launches acts on enqueues, not on replays, so a graph replayed on a GPU that stays oversubscribed can pay the
+ *     bounded wait (~0.3 s) on every replay; capture with the tunable "persistent" = 0, or CAVMD_PERSISTENT=0, there.
  *   - Scalar = double (HOOMD's default HOOMD_LONGREAL_SIZE=64 build).
  *
  * Semantic contract (what "the same result as the reference" means here; file:line = reference)
