@@ -250,6 +250,8 @@ unsigned grid_for(size_t work_items, unsigned tile, int num_cu, int blocks_per_c
     return (unsigned)(g ? g : 1);
 }
 
+constexpr int kScaleBlocksPerCu = 4; // velocity rescale: 256-thread blocks per CU (4 particles per lane and tile)
+
 // Scratch of the scalar reductions (sum |F| / m, kinetic energy): partials + the host-visible scalar.
 int ensure_scalar_scratch(cavmd_workspace* ws)
 {
@@ -1187,9 +1189,9 @@ int cavmd_scale_velocities(cavmd_workspace* ws, void* stream_, cavmd_double4* d_
         return CAVMD_OK;
     hipStream_t stream = (hipStream_t)stream_;
     DeviceGuard guard(ws->device);
-    constexpr int kBlock = 256;
-    const unsigned g = grid_for(n_members, kBlock, ws->num_cu, 8);
-    hipLaunchKernelGGL((scale_velocities_kernel<kBlock>), dim3(g), dim3(kBlock), 0, stream, reinterpret_cast<v2d*>(d_vel),
+    constexpr int kBlock = 256, kUnroll = 4;
+    const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, kScaleBlocksPerCu);
+    hipLaunchKernelGGL((scale_velocities_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream, reinterpret_cast<v2d*>(d_vel),
                        d_members, (unsigned)n_members, alpha);
     return hip_status(hipGetLastError());
 }
@@ -1284,9 +1286,9 @@ int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream_, cavmd_double4* d
                        reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, ws->d_fm_ticket, a,
                        ws->d_bussi, ws->h_bussi_dev, ws->bussi_sequence);
     CAVMD_HIP_TRY(hipGetLastError());
-    const unsigned g2 = grid_for(n_members, kBlock, ws->num_cu, 8);
-    hipLaunchKernelGGL((scale_velocities_dev_kernel<kBlock>), dim3(g2), dim3(kBlock), 0, stream, reinterpret_cast<v2d*>(d_vel),
-                       d_members, (unsigned)n_members, ws->d_bussi);
+    const unsigned g2 = grid_for(n_members, kBlock * kUnroll, ws->num_cu, kScaleBlocksPerCu);
+    hipLaunchKernelGGL((scale_velocities_dev_kernel<kBlock, kUnroll>), dim3(g2), dim3(kBlock), 0, stream,
+                       reinterpret_cast<v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_bussi);
     return hip_status(hipGetLastError());
 }
 
