@@ -20,6 +20,7 @@ from .compute import CavityForceComputeHIP
 
 try:  # HOOMD-blue is optional at import time
     import hoomd  # noqa: F401
+    import hoomd.md  # noqa: F401  (a real package, not a directory that merely happens to be called "hoomd" on sys.path)
     _HAVE_HOOMD = True
 except ImportError:  # an ordinary ModuleNotFoundError in this environment
     _HAVE_HOOMD = False

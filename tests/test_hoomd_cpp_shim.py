@@ -23,9 +23,14 @@ def shim(capi):
     """Builds (idempotent) and imports the stand-in module; `capi` has built libcavmd.so first."""
     subprocess.run(["make", "-C", STANDIN, "-s", "syntax"], check=True)      # the shim alone, -fsyntax-only, module.cc included
     subprocess.run(["make", "-C", STANDIN, "-s", "all"], check=True)
-    if STANDIN not in sys.path:
-        sys.path.insert(0, STANDIN)
-    import _cavitymd_hip_standin as mod
+    # loaded by file path: the stand-in directory holds a folder named "hoomd" (C++ headers) and must not get onto sys.path,
+    # where Python would take it for a (namespace) package of that name
+    import glob
+    import importlib.util
+    path = glob.glob(os.path.join(STANDIN, "_cavitymd_hip_standin*.so"))[0]
+    spec = importlib.util.spec_from_file_location("_cavitymd_hip_standin", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     assert mod.IS_STAND_IN
     return mod
 
