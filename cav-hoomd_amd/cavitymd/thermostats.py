@@ -38,6 +38,9 @@ class BussiReservoir:
         self._members = None   # device tensor of member indices, or None for all particles
         self._n_members = 0
         self._attached = False
+        self._dev_used = False        # some step ran on the device: its counters live there (cavmd_bussi_device_read)
+        self._dev_stream = 0          # stream of the last on-device step
+        self._last_on_device = False  # which path the "instantaneous" counters belong to
 
     # -- attachment (reference: _attach_hook builds the C++ object from the method's filter group) --------------------------
     def attach(self, n_particles: int, members=None, device="cuda") -> None:
@@ -59,6 +62,7 @@ class BussiReservoir:
             self._ws.close()
         self._ws = None
         self._attached = False
+        self._dev_used = self._last_on_device = False
 
     def _set_T(self, timestep: int) -> float:
         return float(self.kT(timestep)) if callable(self.kT) else float(self.kT)
@@ -111,10 +115,10 @@ class BussiReservoir:
 
     def device_state(self):
         """Counters of the on-device path after its last enqueued step (waits for that step's flag, nothing else)."""
-        return self._ws.bussi_device_read(getattr(self, "_dev_stream", 0))
+        return self._ws.bussi_device_read(self._dev_stream)
 
     def _dev(self, field: str) -> float:
-        return getattr(self.device_state(), field) if getattr(self, "_dev_used", False) else 0.0
+        return getattr(self.device_state(), field) if self._dev_used else 0.0
 
     @staticmethod
     def _stream(t: torch.Tensor, stream) -> int:
@@ -139,7 +143,7 @@ class BussiReservoir:
     def instantaneous_reservoir_translational(self) -> float:
         if not self._attached:
             return 0.0
-        if getattr(self, "_last_on_device", False):
+        if self._last_on_device:
             return self._dev("instantaneous_translational")
         return self._state.instantaneous_translational
 
@@ -153,8 +157,8 @@ class BussiReservoir:
 
     def reset_reservoir_energy(self) -> None:
         self._state = _capi.BussiReservoirState()
-        if getattr(self, "_dev_used", False):
-            self._ws.bussi_device_reset(getattr(self, "_dev_stream", 0))
+        if self._dev_used:
+            self._ws.bussi_device_reset(self._dev_stream)
 
 
 def draw_variates(rng: np.random.Generator, translational_dof: float, rotational_dof: float = 0.0):
