@@ -11,7 +11,8 @@ What executes: the reference's own files, loaded by path as a package whose __in
     src/cavitymd/analysis.py              compute_total_dipole_moment (:18-31), compute_density_field (:34-47),
                                           generate_fibonacci_sphere (:50-64), FieldAutocorrelationTracker (wavevectors
                                           :304-311, F(k,t) :359-364), DipoleAutocorrelation (:190-195, :211-240),
-                                          CavityModeTracker.compute_cavity_properties (:1324-1368)
+                                          CavityModeTracker.compute_cavity_properties (:1324-1368),
+                                          EnergyTracker._compute_molecular_kinetic_energy / _compute_cavity_kinetic_energy (:524-598)
     src/cavitymd/simulation.py            AdaptiveTimestepUpdater.act (:33-127): error-tolerance ramp, sum |f_i|/m_i, dt rule
 -- on top of tests/stubs/hoomd, which supplies `import hoomd` with CONTAINERS ONLY (base classes, context managers, one
 decorator; no arithmetic).  The state/snapshot objects below are likewise plain holders of numpy arrays.  Every number
@@ -281,6 +282,27 @@ def main():
         for fn in os.listdir(tmp):
             os.remove(os.path.join(tmp, fn))
         os.rmdir(tmp)
+
+    # ---- 4b. EnergyTracker's internal kinetic energies (analysis.py:524-598): molecular = typeid != 2, cavity = typeid == 2 ----
+    # (the methods are run on a plain holder carrying the three attributes they read; the tracker's constructor only opens
+    # text files)
+    rng = np.random.default_rng(25)
+    for i, (n, where) in enumerate(((501, 500), (4096, 17), (8193, 8192))):
+        tid = (np.arange(n) % 2).astype(np.int32)
+        tid[where] = 2
+        mass = np.where(tid == 0, 15.999, 14.007) * 1822.888
+        mass[where] = 1.0
+        vel = rng.normal(scale=1e-3, size=(n, 3))
+        st = State(np.zeros((n, 3)), tid, np.zeros((n, 3), dtype=np.int32), np.zeros(n), (1, 1, 1), mass=mass, velocity=vel)
+        holder = _NS(sim=Sim(st, hoomd), verbose="normal", cavity_mode_tracker=None)
+        (ke_mol, temp), printed = quiet(analysis.EnergyTracker._compute_molecular_kinetic_energy, holder)
+        assert "Error" not in printed, printed
+        ke_cav, printed = quiet(analysis.EnergyTracker._compute_cavity_kinetic_energy, holder)
+        assert "Error" not in printed, printed
+        out[f"kinetic/{i}/typeid"], out[f"kinetic/{i}/mass"], out[f"kinetic/{i}/velocity"] = tid, mass, vel
+        out[f"kinetic/{i}/molecular"] = np.array([ke_mol, temp])
+        out[f"kinetic/{i}/cavity"] = np.float64(ke_cav)
+        log.append(f"kinetic {i}: N={n} KE_mol={ke_mol:.9e} T={temp:.6f} KE_cav={ke_cav:.9e}")
 
     # ---- 5. adaptive timestep: error-tolerance ramp, sum |f_i| / m_i, dt = sqrt(tol / S) -------------------------------
     rng = np.random.default_rng(30)

@@ -232,3 +232,21 @@ def test_force_mass_sum_and_timestep_rule_match_the_executed_reference(gold):
         tol, dt = float(g["error_tolerance"]), float(g["dt"])
         assert S == pytest.approx(tol / dt**2, rel=1e-13)
         assert prod.adaptive_timestep(tol, S) == pytest.approx(dt, rel=1e-13)
+
+
+def test_group_kinetic_energy_matches_the_executed_reference(gold):
+    """cavmd_kinetic_energy over the molecular group (device index list = every particle whose typeid is not 2) and over the
+    cavity particle alone against EnergyTracker's internal kinetic energies, computed by the reference's own code
+    (analysis.py:524-598).  numpy sums pairwise, the kernel compensated in a fixed tree: 1e-13 relative."""
+    for i in range(3):
+        g = {k: gold[f"kinetic/{i}/{k}"] for k in ("typeid", "mass", "velocity", "molecular", "cavity")}
+        n = len(g["mass"])
+        vel4 = torch.from_numpy(np.concatenate([g["velocity"], g["mass"][:, None]], axis=1)).cuda()
+        ws = _capi.Workspace(n)
+        mol = torch.from_numpy(np.flatnonzero(g["typeid"] != 2).astype(np.int32)).cuda()
+        ke = ws.kinetic_energy(0, vel4.data_ptr(), mol.data_ptr(), mol.numel())
+        assert ke == pytest.approx(g["molecular"][0], rel=1e-13)
+        cav = torch.from_numpy(np.flatnonzero(g["typeid"] == 2).astype(np.int32)).cuda()
+        assert ws.kinetic_energy(0, vel4.data_ptr(), cav.data_ptr(), 1) == pytest.approx(float(g["cavity"]), rel=1e-15)
+        # total = molecular + cavity, all particles without an index list
+        assert ws.kinetic_energy(0, vel4.data_ptr(), None, n) == pytest.approx(g["molecular"][0] + float(g["cavity"]), rel=1e-13)

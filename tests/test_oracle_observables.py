@@ -122,3 +122,23 @@ def test_adaptive_timestep_rule_against_the_executed_reference(gold):
         assert abs(obs.force_mass_sum_exact(g["force_a"] + g["force_b"], g["mass"]) - S) <= 1e-13 * S
         assert np.array_equal(g["tau"], [PC.ps_to_atomic_units(5.0), PC.ps_to_atomic_units(0.5)])
     assert float(gold["adaptive_dt/zero_force/dt"]) == 0.5      # S == 0: dt untouched (simulation.py:88)
+
+
+def test_kinetic_energies_against_the_executed_reference(gold, oracle_mod):
+    """EnergyTracker's internal kinetic energies (analysis.py:524-598): molecular = every particle whose typeid is not 2,
+    cavity = the particle of typeid 2.  The oracle's kinetic energy (oracle/bussi_ref.c, the sum the thermostat consumes) over
+    the same group: numpy sums pairwise, the oracle left to right -> 1e-13 relative; the exactly rounded sum likewise."""
+    bussi = oracle_mod.BussiOracle()
+    for i in range(3):
+        g = {k: gold[f"kinetic/{i}/{k}"] for k in ("typeid", "mass", "velocity", "molecular", "cavity")}
+        vel4 = np.concatenate([g["velocity"], g["mass"][:, None]], axis=1)
+        members = np.flatnonzero(g["typeid"] != 2).astype(np.uint32)
+        ke = bussi.kinetic_energy(vel4, members)
+        assert abs(ke - g["molecular"][0]) <= 1e-13 * g["molecular"][0]
+        hi, _ = bussi.kinetic_energy(vel4, members, exact=True)
+        assert abs(hi - g["molecular"][0]) <= 1e-13 * g["molecular"][0]
+        # the reference's temperature expression, reproduced to the bit from ITS kinetic energy
+        assert (2.0 / 3.0) * g["molecular"][0] / (3 * len(members) * obs.KB_HARTREE_PER_K) == g["molecular"][1]
+        cav = np.flatnonzero(g["typeid"] == 2)
+        ke_c, _, _, _ = obs.cavity_mode(g["velocity"], g["mass"], g["typeid"], 0.0, L_typeid=2)
+        assert len(cav) == 1 and ke_c == float(g["cavity"])
