@@ -195,9 +195,11 @@ struct BlockRange
     size_t first, step, tail_base;
     unsigned nfull, tail_count;
 };
-//   hybrid    (partition 2) the full rounds strided -- every block the same floor(full_tiles / G) tiles -- and what is left
-//             (fewer than G tiles' worth of particles) cut into G contiguous shares of whole 64-particle units, one ragged
-//             tile per block: equal work to within 64 particles AND the strided sweep for all but the last round.
+//   hybrid    (partition 2; MEASURED AND REJECTED in round 3, micro-benchmark only) the full rounds strided -- every block the
+//             same floor(full_tiles / G) tiles -- and what is left (fewer than G tiles' worth of particles) cut into G
+//             contiguous shares of whole 64-particle units, one ragged tile per block: equal work to within 64 particles AND
+//             the strided sweep for all but the last round.  20.5 vs 19.8 us at N = 1e6: the slowest block is not the one
+//             with a tile more (profiles/r03/microbench_persistent_hybrid_partition_*.txt).
 template <unsigned TILE>
 __device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsigned b, int balanced)
 {
@@ -243,10 +245,14 @@ __device__ __forceinline__ BlockRange block_range(unsigned N, unsigned G, unsign
 
 extern __shared__ __attribute__((aligned(16))) double s_dyn_charge[];
 
-// EARLYZ: half of every force entry -- the odd 16-byte chunk (F_z, w) = (0, 0) of every particle that is not the photon --
-// does not depend on the total.  With EARLYZ waves 1..3 of a block write those chunks of the block's own tiles WHILE wave 0
-// runs the hand-off, i.e. while the memory system would otherwise sit idle (~3-4 us per evaluation at N = 1e6), and phase 2
-// writes the even chunks only (plus the photon's odd chunk, over the zero).
+// EARLYZ (MEASURED AND REJECTED in round 3; instantiated by the micro-benchmark only, the library uses EARLYZ = 0): half of
+// every force entry -- the odd 16-byte chunk (F_z, w) = (0, 0) of every particle that is not the photon -- does not depend on
+// the total.  With EARLYZ waves 1..3 of a block write those chunks of the block's own tiles WHILE wave 0 runs the hand-off,
+// i.e. while the memory system would otherwise sit idle (~3-4 us per evaluation at N = 1e6), and phase 2 writes the even
+// chunks only (plus the photon's odd chunk, over the zero).  Result: 26.5 instead of 19.8 us at N = 1e6 (34.4 with
+// non-temporal early stores), slower at every size from 1e5 to 2e6 -- both passes store 16 bytes out of every 32, and the
+// memory side pays per line touched (profiles/r03/microbench_persistent_early_zero_chunks_*.txt).  Kept so that the table can
+// be reproduced (`CAVMD_TRY_EARLYZ=1 ./microbench_persistent`).
 template <int BLOCK, int UNROLL, int NT_STORE, bool FAULT = false, int EARLYZ = 0>
 __global__ __launch_bounds__(BLOCK) void cavity_persistent_kernel(AosInputT<2> in, unsigned N, double Lx, double Ly, double Lz,
                                                                   DeviceParams prm, int L_typeid, SyncState st,
