@@ -167,7 +167,7 @@ def _declare(lib):
         lib.cavmd_bussi_step.restype = ci
         lib.cavmd_bussi_step_device.argtypes = [vp, vp, vp, vp, sz] + [dbl] * 6
         lib.cavmd_bussi_step_device.restype = ci
-        lib.cavmd_bussi_device_read.argtypes = [vp, vp, P(BussiDeviceState)]
+        lib.cavmd_bussi_device_read.argtypes = [vp, P(BussiDeviceState)]
         lib.cavmd_bussi_device_read.restype = ci
         lib.cavmd_bussi_device_reset.argtypes = [vp, vp]
         lib.cavmd_bussi_device_reset.restype = ci
@@ -331,9 +331,9 @@ class Workspace:
                                                 float(dof), float(deltaT), float(set_T), float(tau), float(normal_variate),
                                                 float(gamma_variate)), "cavmd_bussi_step_device")
 
-    def bussi_device_read(self, stream: int = 0) -> "BussiDeviceState":
+    def bussi_device_read(self) -> "BussiDeviceState":
         out = BussiDeviceState()
-        check(self._lib.cavmd_bussi_device_read(self._h, ctypes.c_void_p(stream), ctypes.byref(out)), "cavmd_bussi_device_read")
+        check(self._lib.cavmd_bussi_device_read(self._h, ctypes.byref(out)), "cavmd_bussi_device_read")
         return out
 
     def bussi_device_reset(self, stream: int = 0) -> None:

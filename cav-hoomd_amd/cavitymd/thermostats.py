@@ -115,7 +115,7 @@ class BussiReservoir:
 
     def device_state(self):
         """Counters of the on-device path after its last enqueued step (waits for that step's flag, nothing else)."""
-        return self._ws.bussi_device_read(self._dev_stream)
+        return self._ws.bussi_device_read()
 
     def _dev(self, field: str) -> float:
         return getattr(self.device_state(), field) if self._dev_used else 0.0

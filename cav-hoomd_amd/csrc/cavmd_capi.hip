@@ -138,6 +138,7 @@ struct cavmd_workspace
     HostBussi* h_bussi_dev = nullptr;
     uint64_t bussi_sequence = 0;
     uint64_t bussi_refused_seen = 0;  // refusals already reported to the caller
+    hipStream_t bussi_stream = nullptr; // stream of the last enqueued step: the one whose idleness ends a wait for its flag
 };
 
 namespace
@@ -1282,6 +1283,7 @@ int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream_, cavmd_double4* d
     a.gamma_variate = gamma_variate;
     const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 1);
     ws->bussi_sequence += 1;
+    ws->bussi_stream = stream;
     hipLaunchKernelGGL((bussi_kinetic_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
                        reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, ws->d_fm_ticket, a,
                        ws->d_bussi, ws->h_bussi_dev, ws->bussi_sequence);
@@ -1292,14 +1294,14 @@ int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream_, cavmd_double4* d
     return hip_status(hipGetLastError());
 }
 
-int cavmd_bussi_device_read(cavmd_workspace* ws, void* stream_, cavmd_bussi_device_state* out)
+int cavmd_bussi_device_read(cavmd_workspace* ws, cavmd_bussi_device_state* out)
 {
     if (!ws || !out)
         return CAVMD_ERR_INVALID_VALUE;
     memset(out, 0, sizeof(*out));
     if (!ws->d_bussi || ws->bussi_sequence == 0)
         return CAVMD_OK;
-    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t stream = ws->bussi_stream; // the stream the last step went to, whatever stream the caller is on now
     DeviceGuard guard(ws->device);
     const uint64_t want = ws->bussi_sequence;
     for (;;)
@@ -1344,7 +1346,7 @@ int cavmd_bussi_device_reset(cavmd_workspace* ws, void* stream_)
     DeviceGuard guard(ws->device);
     // wait for the last step's publication first so that the host copy can be reset consistently
     cavmd_bussi_device_state unused;
-    const int st = cavmd_bussi_device_read(ws, stream_, &unused);
+    const int st = cavmd_bussi_device_read(ws, &unused);
     if (st != CAVMD_OK && st != CAVMD_ERR_BAD_PARAMS)
         return st;
     CAVMD_HIP_TRY(hipMemsetAsync(ws->d_bussi, 0, sizeof(BussiDevice), stream));

@@ -287,7 +287,7 @@ typedef struct cavmd_bussi_device_state
 } cavmd_bussi_device_state;
 /* State after the last enqueued cavmd_bussi_step_device: spins on the flag that step publishes into mapped host memory (no
  * copy, no stream synchronisation); before any step: zeros.  CAVMD_ERR_BAD_PARAMS (once) if a step was refused since the last call. */
-CAVMD_API int cavmd_bussi_device_read(cavmd_workspace* ws, void* stream, cavmd_bussi_device_state* out);
+CAVMD_API int cavmd_bussi_device_read(cavmd_workspace* ws, cavmd_bussi_device_state* out);
 /* reset_reservoir_energy() of the reference's Python class: zero the counters (ordered on `stream`). */
 CAVMD_API int cavmd_bussi_device_reset(cavmd_workspace* ws, void* stream);
 

@@ -242,15 +242,15 @@ def test_on_device_step_refuses_zero_momenta_and_keeps_the_array():
     ws = _capi.Workspace(n)
     ws.bussi_step_device(0, dvel.data_ptr(), None, n, 3.0 * n, 0.02, 3e-4, 0.5, 0.3, 7000.0)
     with pytest.raises(_capi.CavmdError) as e:
-        ws.bussi_device_read(0)
+        ws.bussi_device_read()
     assert e.value.status == _capi.CAVMD_ERR_BAD_PARAMS
-    st = ws.bussi_device_read(0)                                   # reported once
+    st = ws.bussi_device_read()                                   # reported once
     assert st.refused == 1 and st.steps == 0 and st.last_alpha == 1.0 and st.reservoir_translational == 0.0
     torch.cuda.synchronize()
     assert np.array_equal(dvel.cpu().numpy(), vel)
     # dof == 0: alpha = 1 by the rule itself (:183-184), not an error
     ws.bussi_step_device(0, dvel.data_ptr(), None, n, 0.0, 0.02, 3e-4, 0.5, 0.3, 0.0)
-    st = ws.bussi_device_read(0)
+    st = ws.bussi_device_read()
     assert st.steps == 1 and st.last_alpha == 1.0
     # argument validation, as the other entry points
     with pytest.raises(_capi.CavmdError):
