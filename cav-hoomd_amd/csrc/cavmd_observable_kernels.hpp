@@ -468,6 +468,14 @@ __device__ __forceinline__ DD block_reduce_dd1(DD v)
 // partials t, t + BLOCK, ...; then the block tree) -- a fixed order whichever block it is, so the result is bit-reproducible
 // -- and resets the ticket counter for the next call.  Replaces a second launch (host call + kernel boundary + ramp:
 // 23 -> 15 us per kinetic-energy call at N = 1e6).  Returns true in the folding block; its total is valid in thread 0.
+// Ordering: this is NOT a release/acquire pair of the memory model but the hand-off form MI355X_MICROARCH.md lists as measured
+// valid on gfx950 (inter-workgroup visibility, hand-off table, row 1): every byte handed off is stored `sc1` (write-through:
+// the 8-byte agent-scope stores below), the one storing wave runs `s_waitcnt vmcnt(0)` after them, the same lane then signals
+// with an agent-scope atomic add, the consumer is "the workgroup whose add came last, told by the value its add returned", it
+// loads only after that add has returned (the other waves behind a workgroup barrier it then joins), and every load of the
+// handed-off bytes is `sc1`.  A release fence before the add and an acquire fence in the folding block would write back and
+// invalidate a whole L2 / L1 per block (~1.7 us each, on the critical path of a 9 us kernel that has written 16 bytes).
+// A launch that dies half-way leaves the counter part-way: the host puts it back when it reports the failure (wait_scalar).
 template <int BLOCK>
 __device__ __forceinline__ bool fold_by_last_block(DD& acc, double* __restrict__ part, unsigned* __restrict__ ticket)
 {
