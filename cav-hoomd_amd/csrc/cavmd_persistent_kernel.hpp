@@ -55,7 +55,13 @@ constexpr unsigned kRepairRounds = 4096; // the last block of a starved evaluati
 
 constexpr int kGroup = 16;           // blocks per first-level group = lanes of a DPP row
 constexpr unsigned kMaxPersistGrid = kGroup * kGroup;
-constexpr unsigned kGroupCopies = 8; // the group totals are published in 8 copies; block b polls copy b % 8, so a line of
+#ifndef CAVMD_GROUP_COPIES // (micro-benchmark sweeps only)
+#define CAVMD_GROUP_COPIES 8
+#endif
+#ifndef CAVMD_POLL_SLEEP
+#define CAVMD_POLL_SLEEP 1
+#endif
+constexpr unsigned kGroupCopies = CAVMD_GROUP_COPIES; // the group totals are published in 8 copies; block b polls copy b % 8, so a line of
                                      // group records has 32 pollers instead of 256 (a one-to-255 broadcast through one
                                      // line costs ~1 us more than through lines with 32 pollers: scripts/dev/pingpong.hip)
 
@@ -169,7 +175,8 @@ __device__ __forceinline__ bool gather_records(const unsigned long long* slab, u
             break;
         if (spins >= max_rounds)
             return false;
-        __builtin_amdgcn_s_sleep(1);
+        if (CAVMD_POLL_SLEEP > 0)
+            __builtin_amdgcn_s_sleep(CAVMD_POLL_SLEEP);
     }
 #pragma unroll
     for (int j = 0; j < ROUNDS; ++j)
