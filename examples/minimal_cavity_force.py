@@ -59,6 +59,12 @@ def main():
     for step in range(3):
         alpha, _ = bussi.step(step, 1.0, vel4, translational_dof=3.0 * (n - 1) - 3.0, rng=rng)
         print(f"thermostat step {step}: alpha={alpha:.6f} reservoir={bussi.total_reservoir_energy:.6e}")
+    # the same step without a host round trip: kinetic energy, the rule and the rescaling all on the device, asynchronous;
+    # the counters are fetched when they are read
+    for step in range(3, 6):
+        bussi.step_async(step, 1.0, vel4, translational_dof=3.0 * (n - 1) - 3.0, rng=rng)
+    print(f"after three on-device steps: last alpha={bussi.device_state().last_alpha:.6f} "
+          f"reservoir={bussi.total_reservoir_energy:.6e}")
 
 
 if __name__ == "__main__":
