@@ -516,11 +516,6 @@ int cavmd_destroy(cavmd_workspace* ws)
 
 namespace
 {
-// A single-launch evaluation whose blocks were not resident together (other grids held the CUs) either got completed by its
-// last block alone (kSyncRepaired: results valid, it just took a second) or failed (kSyncFailed: NaN forces) -- see the
-// bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- suspends the
-// single-launch path for this workspace: what starved the grid is a property of how the GPU is shared at the moment, not of
-// one step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
 // Where the kernels publish the result block for the host: the workspace's mapped block -- or, in the test-hooks build with
 // "debug_skip_publish" set, a scratch block the host never looks at (what a launch that died on the device looks like).
 inline HostResult* host_block(cavmd_workspace* ws)
@@ -532,6 +527,11 @@ inline HostResult* host_block(cavmd_workspace* ws)
     return ws->h_result_dev;
 }
 
+// A single-launch evaluation whose blocks were not resident together (other grids held the CUs) either got completed by its
+// last block alone (kSyncRepaired: results valid, it just took a second) or failed (kSyncFailed: NaN forces) -- see the
+// bail path of cavity_persistent_kernel.  Whoever notices first -- the next enqueue or the result read -- suspends the
+// single-launch path for this workspace: what starved the grid is a property of how the GPU is shared at the moment, not of
+// one step, and the two-launch path does not depend on residency.  Returns 0 (nothing happened), kSyncRepaired or kSyncFailed.
 unsigned consume_sync_timeout(cavmd_workspace* ws)
 {
     if (!ws->h_result || !__atomic_load_n(&ws->h_result->sync_error, __ATOMIC_ACQUIRE))
