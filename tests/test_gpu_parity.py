@@ -1028,3 +1028,35 @@ def test_launches_queued_behind_an_evaluation_nobody_could_complete_fail_as_a_wh
     assert np.array_equal(np.array(ws.result().dipole[:]), want_d)
     torch.cuda.synchronize()
     assert torch.equal(frc[0].view(torch.int64), want.view(torch.int64))
+
+
+def test_replays_of_a_captured_graph_behind_an_uncompleted_evaluation_fail_as_a_whole():
+    """The same for a captured graph: the host-side recovery does not reach into it, so after a replay that nobody could
+    complete every further replay has to fail by itself -- at once, as a whole, with nothing published -- until the caller
+    captures again.  What tells a replay from the failed one is the launch nonce (the address of the replay's own AQL
+    packet): kernel arguments, sequence number included, are frozen in a graph."""
+    n = 3_001                                                       # one-hop grid: the silent block completes on its own,
+    cfg, pos, chg, img = _device_inputs(n, seed=91, photon_at=7)    # the give-up count can never reach G
+    prm = _capi.make_params(0.0091, 1e-3, 1.0)
+    frc = torch.full((n, 4), 7.0, dtype=torch.float64, device="cuda")
+    ws = _capi.Workspace(n, hooks=True)
+    for k, v in (("persistent", 1), ("small_system_max_n", 0), ("debug_spin_limit", 5000), ("debug_silent_block", 1)):
+        ws.set_tunable(k, v)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ws.compute_hoomd(torch.cuda.current_stream().cuda_stream, n, pos.data_ptr(), chg.data_ptr(), img.data_ptr(), cfg["box"], 2,
+                         prm, frc.data_ptr())
+    graph.replay()                                                  # starves itself, ends uncompleted: poison stays
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(frc).any()) and not bool(torch.isnan(frc).all())
+    for _ in range(3):
+        frc.fill_(7.0)
+        t0 = time.perf_counter()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.05                      # no bounded wait: the replay gives up at entry
+        assert bool(torch.isnan(frc).all())
+    with pytest.raises(_capi.CavmdError) as e:
+        ws.result()
+    assert e.value.status == _capi.CAVMD_ERR_SYNC_TIMEOUT
