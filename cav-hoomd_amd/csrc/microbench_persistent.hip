@@ -18,11 +18,16 @@
 
 constexpr int kStampSlots = 8;
 __device__ unsigned long long g_pstamps[4096 * kStampSlots];
+__device__ unsigned g_xcc[4096];
 #define CAVMD_PSTAMP(k)                                                \
     do                                                                 \
     {                                                                  \
         if (threadIdx.x == 0)                                          \
+        {                                                              \
             g_pstamps[blockIdx.x * kStampSlots + (k)] = wall_clock64(); \
+            if ((k) == 0)                                              \
+                g_xcc[blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF; /* HW_REG_XCC_ID[3:0] */ \
+        }                                                              \
     } while (0)
 #include "cavmd_kernels.hpp"
 
@@ -82,6 +87,8 @@ int main(int argc, char** argv)
         CHECK(hipMemcpy(d_chg[f], h_chg.data(), N * 8, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_img[f], h_img.data(), N * 12, hipMemcpyHostToDevice));
     }
+    for (int f = 0; f < frames; ++f)
+        printf("frame %d: pos %p  force %p  charge %p  image %p\n", f, (void*)d_pos[f], (void*)d_frc[f], (void*)d_chg[f], (void*)d_img[f]);
     const unsigned max_parts = CU * 16;
     double* d_part; int* d_ipart; cavmd_result* d_res; HostResult* d_hres;
     unsigned long long* d_gran; unsigned* d_epoch;
@@ -297,6 +304,8 @@ int main(int argc, char** argv)
         const char* names[8] = {"start", "phase1 done", "block tree done", "total in wave 0", "scalars in LDS",
                                 "barrier passed", "stores issued", "group level done"};
         std::vector<std::vector<double>> med(8), mx(8), mnv(8);
+        std::vector<std::vector<double>> xcc_p1(30, std::vector<double>(8, 0.0));
+        std::vector<int> xcc_frame(30, 0);
         for (int rep = 0; rep < 30; ++rep)
         {
             for (int k = 0; k < 12; ++k) persist((rep + k) % frames, 1, timeline_partition, timeline_earlyz); // steady state: the stamps are those of the last launch
@@ -305,6 +314,15 @@ int main(int argc, char** argv)
             CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_pstamps), sizeof(unsigned long long) * h.size()));
             unsigned long long t0 = ~0ull;
             for (unsigned b = 0; b < g1; ++b) t0 = std::min(t0, h[b * kStampSlots]);
+            {
+                std::vector<unsigned> hx(4096);
+                CHECK(hipMemcpyFromSymbol(hx.data(), HIP_SYMBOL(g_xcc), sizeof(unsigned) * hx.size()));
+                std::vector<double> sum(8, 0.0); std::vector<int> cnt(8, 0);
+                for (unsigned b = 0; b < g1; ++b) { const unsigned x = hx[b] & 7; sum[x] += (double)(h[b * kStampSlots + 1] - t0) * 0.01; cnt[x]++; }
+                for (int x = 0; x < 8; ++x) xcc_p1[rep][x] = cnt[x] ? sum[x] / cnt[x] : 0.0;
+                xcc_frame[rep] = (rep + 11) % frames;
+                if (rep == 29) { printf("  blocks per XCC_ID in the last run:"); for (int x = 0; x < 8; ++x) printf(" %d", cnt[x]); printf("\n"); }
+            }
             if (rep == 29 && getenv("CAVMD_DUMP_BLOCKS"))
             {
                 printf("  per block: b tiles start phase1_done tree_done\n");
@@ -339,6 +357,8 @@ int main(int argc, char** argv)
                 med[k].push_back(v[g1 / 2]); mx[k].push_back(v.back()); mnv[k].push_back(v.front());
             }
         }
+        printf("  mean phase-1-done per XCC_ID (us), one row per run (12 back-to-back launches each, stamps of the last):\n");
+        for (int rep = 0; rep < 30; ++rep) { printf("   run %2d (frame %d):", rep, xcc_frame[rep]); for (int x = 0; x < 8; ++x) printf(" %6.2f", xcc_p1[rep][x]); printf("\n"); }
         printf("time line, single launch, grid %u (us after the first block's start; median over 30 runs of the per-run min / median / max over blocks)\n",
                g1);
         for (int k : {0, 1, 2, 7, 3, 4, 5, 6})
