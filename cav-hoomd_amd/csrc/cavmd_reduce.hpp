@@ -33,6 +33,19 @@ constexpr int kNumPartInts = 2;    // min L index, count of L-typed particles
 // (hi, lo) += t, error-free (Knuth TwoSum; 6 flops + 1)
 __device__ __forceinline__ void dd_acc(double& hi, double& lo, double t)
 {
+#if defined(CAVMD_DIAG_ACC_COST) // micro-benchmark diagnostics only (WRONG or padded arithmetic): what the accumulation costs
+#if CAVMD_DIAG_ACC_COST == 0     // plain double sum: 1 instruction instead of 7
+    hi += t;
+    return;
+#else                            // the compensated sum TWICE (the second into a dead-looking but live copy): 14 instead of 7
+    {
+        const double s2 = lo + t;
+        const double b2 = s2 - lo;
+        const double e2 = (lo - (s2 - b2)) + (t - b2);
+        asm volatile("" ::"v"(s2), "v"(e2));
+    }
+#endif
+#endif
     const double s = hi + t;
     const double bb = s - hi;
     const double e = (hi - (s - bb)) + (t - bb);
