@@ -286,7 +286,10 @@ typedef struct cavmd_bussi_device_state
     uint64_t refused;                   /* steps refused for zero kinetic energy */
 } cavmd_bussi_device_state;
 /* State after the last enqueued cavmd_bussi_step_device: spins on the flag that step publishes into mapped host memory (no
- * copy, no stream synchronisation); before any step: zeros.  CAVMD_ERR_BAD_PARAMS (once) if a step was refused since the last call. */
+ * copy, no stream synchronisation; it watches the stream that step was enqueued on); before any step: zeros.
+ * CAVMD_ERR_BAD_PARAMS (once) if a step was refused since the last call.  Steps captured into a hipGraph replay correctly on
+ * the device (alpha and the counters live there); the flag, however, carries the sequence number frozen at capture, so after
+ * replays synchronise the stream (or device) before reading. */
 CAVMD_API int cavmd_bussi_device_read(cavmd_workspace* ws, cavmd_bussi_device_state* out);
 /* reset_reservoir_energy() of the reference's Python class: zero the counters (ordered on `stream`). */
 CAVMD_API int cavmd_bussi_device_reset(cavmd_workspace* ws, void* stream);
