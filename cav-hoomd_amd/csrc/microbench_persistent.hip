@@ -79,10 +79,25 @@ int main(int argc, char** argv)
     std::vector<cavmd_double4*> d_pos(frames), d_frc(frames);
     std::vector<double*> d_chg(frames);
     std::vector<cavmd_int3*> d_img(frames);
+    // CAVMD_SLAB=1: all frames carved from ONE allocation (2 MiB-aligned pieces) instead of four hipMallocs per frame -- a
+    // diagnostic for the placement dependence of the phase-1 spread
+    char* slab = nullptr;
+    size_t slab_off = 0;
+    auto piece = [&](size_t bytes) { char* p = slab + slab_off; slab_off += (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1); return p; };
+    if (getenv("CAVMD_SLAB"))
+        CHECK(hipMalloc((void**)&slab, (size_t)frames * (N * 84 + (8u << 20)) + (2u << 20)));
     for (int f = 0; f < frames; ++f)
     {
+        if (slab)
+        {
+            d_pos[f] = (cavmd_double4*)piece(N * 32); d_frc[f] = (cavmd_double4*)piece(N * 32);
+            d_chg[f] = (double*)piece(N * 8);          d_img[f] = (cavmd_int3*)piece(N * 12);
+        }
+        else
+        {
         CHECK(hipMalloc((void**)&d_pos[f], N * 32)); CHECK(hipMalloc((void**)&d_frc[f], N * 32));
         CHECK(hipMalloc((void**)&d_chg[f], N * 8));  CHECK(hipMalloc((void**)&d_img[f], N * 12));
+        }
         CHECK(hipMemcpy(d_pos[f], h_pos.data(), N * 32, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_chg[f], h_chg.data(), N * 8, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(d_img[f], h_img.data(), N * 12, hipMemcpyHostToDevice));
