@@ -414,8 +414,8 @@ def thermostat_measurement(n, device, steps=50, warmup=5):
     return {"N": n, "kinetic_energy_us": 1e6 * t_ke, "kinetic_energy_GBps": 32 * n / t_ke / 1e9, "full_step_us": 1e6 * t_step,
             "full_step_on_device_us": 1e6 * t_dev, "full_step_on_device_GBps": 96 * n / t_dev / 1e9,
             "note": "host rule: KE = one kernel, the number reaches the host through a mapped flag, host arithmetic, then the "
-                    "rescale kernel.  on device (cavmd_bussi_step_device): the KE kernel's folding block evaluates the rule, the "
-                    "rescale kernel reads alpha from device memory; back to back, no host round trip; 96 N bytes per step "
+                    "rescale kernel.  on device (cavmd_bussi_step_device): one partial per block, then every block of the rescale "
+                    "kernel folds them, evaluates the rule and rescales; back to back, no host round trip; 96 N bytes per step "
                     "(32 N read + 64 N read/write).  Kernel times: profiles/r03/observables_kernel_stats.csv"}
 
 

@@ -1284,13 +1284,13 @@ int cavmd_bussi_step_device(cavmd_workspace* ws, void* stream_, cavmd_double4* d
     const unsigned g = grid_for(n_members, kBlock * kUnroll, ws->num_cu, 1);
     ws->bussi_sequence += 1;
     ws->bussi_stream = stream;
-    hipLaunchKernelGGL((bussi_kinetic_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
-                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, ws->d_fm_ticket, a,
-                       ws->d_bussi, ws->h_bussi_dev, ws->bussi_sequence);
+    hipLaunchKernelGGL((kinetic_partials_kernel<kBlock, kUnroll>), dim3(g), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part);
     CAVMD_HIP_TRY(hipGetLastError());
     const unsigned g2 = grid_for(n_members, kBlock * kUnroll, ws->num_cu, kScaleBlocksPerCu);
-    hipLaunchKernelGGL((scale_velocities_dev_kernel<kBlock, kUnroll>), dim3(g2), dim3(kBlock), 0, stream,
-                       reinterpret_cast<v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_bussi);
+    hipLaunchKernelGGL((bussi_rescale_fused_kernel<kBlock, kUnroll>), dim3(g2), dim3(kBlock), 0, stream,
+                       reinterpret_cast<v2d*>(d_vel), d_members, (unsigned)n_members, ws->d_fm_part, g, a, ws->d_bussi,
+                       ws->h_bussi_dev, ws->bussi_sequence);
     return hip_status(hipGetLastError());
 }
 
@@ -1312,10 +1312,7 @@ int cavmd_bussi_device_read(cavmd_workspace* ws, cavmd_bussi_device_state* out)
         if (q == hipSuccess)
         {
             if (__atomic_load_n(&ws->h_bussi->ready, __ATOMIC_ACQUIRE) != want)
-            {
-                (void)hipMemsetAsync(ws->d_fm_ticket, 0, 128, stream); // as wait_scalar: a launch that never published
-                return (int)hipErrorLaunchFailure;
-            }
+                return (int)hipErrorLaunchFailure; // a launch that never published
             break;
         }
         if (q != hipErrorNotReady)

@@ -626,7 +626,7 @@ struct BussiDevice
 {
     double reservoir;     // cumulative energy handed to the bath, sum of KE (1 - alpha^2)   (src/BussiReservoirThermostat.h:86-95)
     double instantaneous; // the last step's share
-    double alpha;         // the last step's factor: what the rescale kernel of the same step reads
+    double alpha;         // the last step's factor
     double kinetic;       // the kinetic energy the last step saw
     uint64_t steps;       // steps applied
     uint64_t errors;      // steps refused: degrees of freedom without kinetic energy ("requires non-zero initial momenta", :57-61)
@@ -641,37 +641,19 @@ struct BussiStepArgs
     double dof, c, set_T, normal_variate, gamma_variate;
 };
 
+// Launch 1 of the on-device step: one double-double partial per block, nothing else (plain stores; the kernel boundary makes
+// them visible to launch 2).  No ticket, no last-block fold: that latency-bound tail (~3.5 us of the 9 us kinetic_fused_kernel
+// takes at N = 1e6) is only needed when ONE kernel has to hand the total to the host.
 template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void bussi_kinetic_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
-                                                              unsigned n, double* __restrict__ part,
-                                                              unsigned* __restrict__ ticket, BussiStepArgs a,
-                                                              BussiDevice* __restrict__ state, HostBussi* __restrict__ host,
-                                                              uint64_t sequence)
+__global__ __launch_bounds__(BLOCK) void kinetic_partials_kernel(const v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                                 unsigned n, double* __restrict__ part)
 {
     DD acc = kinetic_partial<BLOCK, UNROLL>(vel2, members, n);
     acc = block_reduce_dd1<BLOCK>(acc);
-    if (fold_by_last_block<BLOCK>(acc, part, ticket) && threadIdx.x == 0)
+    if (threadIdx.x == 0)
     {
-        const double K = 0.5 * (acc.hi + acc.lo);
-        BussiDevice s = *state;
-        s.kinetic = K;
-        if (a.dof != 0 && K == 0)
-        {
-            s.alpha = 1.0; // nothing is rescaled, the refusal is counted and reported by cavmd_bussi_device_read
-            s.instantaneous = 0.0;
-            s.errors += 1;
-        }
-        else
-        {
-            s.alpha = bussi_alpha_from_c(K, a.dof, a.c, a.set_T, a.normal_variate, a.gamma_variate);
-            const double delta = K * (1.0 - s.alpha * s.alpha);
-            s.reservoir += delta;
-            s.instantaneous = delta;
-            s.steps += 1;
-        }
-        *state = s; // the rescale kernel behind this one (same stream) reads alpha from here
-        host->state = s;
-        __hip_atomic_store(&host->ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        part[blockIdx.x] = acc.hi;
+        part[gridDim.x + blockIdx.x] = acc.lo;
     }
 }
 
@@ -722,13 +704,53 @@ __global__ __launch_bounds__(BLOCK) void scale_velocities_kernel(v2d* __restrict
     scale_velocities_body<BLOCK, UNROLL>(vel2, members, n, alpha);
 }
 
-// the same with alpha read from the thermostat's device state (written by bussi_kinetic_kernel earlier in the stream);
-// alpha == 1 (dt == 0 or a refused step) leaves the array untouched -- multiplying by 1.0 would give the same bits
+// Launch 2 of the on-device step: EVERY block folds launch 1's partials itself, in the order fold_by_last_block uses (thread t:
+// partials t, t + BLOCK, ...; then the block tree), so every block holds the kinetic energy cavmd_kinetic_energy would return,
+// bit for bit, evaluates the rule (a pure function of it and of the arguments: the same alpha in every block) and rescales its
+// share of the group -- the structure of the two-launch force path (force_map_aos_fused_kernel).  Block 0 also keeps the books:
+// reservoir counters in device memory and their copy, with the step's sequence number, in mapped host memory.  alpha == 1
+// (a refused step, or 0 degrees of freedom) leaves the array untouched -- multiplying by 1.0 would give the same bits.
 template <int BLOCK, int UNROLL>
-__global__ __launch_bounds__(BLOCK) void scale_velocities_dev_kernel(v2d* __restrict__ vel2, const unsigned* __restrict__ members,
-                                                                     unsigned n, const BussiDevice* __restrict__ state)
+__global__ __launch_bounds__(BLOCK) void bussi_rescale_fused_kernel(v2d* __restrict__ vel2, const unsigned* __restrict__ members,
+                                                                    unsigned n, const double* __restrict__ part, unsigned G1,
+                                                                    BussiStepArgs a, BussiDevice* __restrict__ state,
+                                                                    HostBussi* __restrict__ host, uint64_t sequence)
 {
-    const double alpha = state->alpha;
+    __shared__ double s_alpha;
+    DD tot {0.0, 0.0};
+    for (unsigned p = threadIdx.x; p < G1; p += BLOCK)
+        dd_merge(tot.hi, tot.lo, part[p], part[G1 + p]);
+    tot = block_reduce_dd1<BLOCK>(tot);
+    if (threadIdx.x == 0)
+    {
+        const double K = 0.5 * (tot.hi + tot.lo);
+        const bool refused = (a.dof != 0 && K == 0); // "Bussi thermostat requires non-zero initial momenta." (:57-61)
+        const double alpha = refused ? 1.0 : bussi_alpha_from_c(K, a.dof, a.c, a.set_T, a.normal_variate, a.gamma_variate);
+        s_alpha = alpha;
+        if (blockIdx.x == 0)
+        {
+            BussiDevice s = *state;
+            s.kinetic = K;
+            s.alpha = alpha;
+            if (refused)
+            {
+                s.instantaneous = 0.0; // nothing is rescaled; counted, and reported by the next cavmd_bussi_device_read
+                s.errors += 1;
+            }
+            else
+            {
+                const double delta = K * (1.0 - alpha * alpha); // src/BussiReservoirThermostat.h:86-95
+                s.reservoir += delta;
+                s.instantaneous = delta;
+                s.steps += 1;
+            }
+            *state = s;
+            host->state = s;
+            __hip_atomic_store(&host->ready, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    const double alpha = s_alpha;
     if (alpha == 1.0)
         return;
     scale_velocities_body<BLOCK, UNROLL>(vel2, members, n, alpha);

@@ -267,7 +267,8 @@ CAVMD_API int cavmd_bussi_step(cavmd_bussi_reservoir* state, double K_translatio
 
 /* The same translational step ENTIRELY ON THE DEVICE and asynchronous (round 3): kinetic energy of the group -> alpha ->
  * reservoir counters -> velocities *= alpha, as two kernels enqueued on `stream` with no host round trip in between (the
- * kernel that folds the kinetic energy evaluates the rule and leaves alpha in device memory for the rescale kernel).  What
+ * first leaves one partial sum per workgroup; every workgroup of the second folds them in a fixed order, evaluates the rule
+ * itself and rescales its share; no atomics, no last-workgroup tail).  What
  * getRescalingFactorsOne + the integration method's rescale do per step (src/BussiReservoirThermostat.h:43-98, 177-225) for the
  * translational degrees of freedom; rotational ones stay on the host path above (cavmd_bussi_step).  The rule runs the same
  * source function as cavmd_bussi_rescale_factor (c = exp(-dt / tau) is taken on the host): same bits for the same kinetic energy.
