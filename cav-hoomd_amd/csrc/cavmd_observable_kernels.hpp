@@ -661,39 +661,63 @@ __global__ __launch_bounds__(BLOCK) void kinetic_partials_kernel(const v2d* __re
 // 2 * UNROLL 16-byte loads of a lane are issued before the first store (the grid-stride loop this replaces, one particle per
 // lane and round trip, ran at 5.2 TB/s of read + write at N = 1e7; see profiles/r03/observables_kernel_stats_1e7.csv).
 template <int BLOCK, int UNROLL>
+struct ScaleTile
+{
+    v2d xy[UNROLL], zw[UNROLL];
+    size_t j[UNROLL]; // particle index per slot, (size_t)-1 = padding
+};
+template <int BLOCK, int UNROLL>
+__device__ __forceinline__ void scale_tile_load(const v2d* __restrict__ vel2, const unsigned* __restrict__ members, unsigned n,
+                                                unsigned t, ScaleTile<BLOCK, UNROLL>& r)
+{
+    const size_t base = (size_t)t * (BLOCK * UNROLL) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+    {
+        const size_t k = base + (size_t)u * BLOCK;
+        r.j[u] = k < n ? (members ? (size_t)members[k] : k) : (size_t)-1;
+        if (r.j[u] != (size_t)-1)
+        {
+            r.xy[u] = vel2[2 * r.j[u]];
+            r.zw[u] = vel2[2 * r.j[u] + 1];
+        }
+    }
+}
+template <int BLOCK, int UNROLL>
+__device__ __forceinline__ void scale_tile_store(v2d* __restrict__ vel2, double alpha, ScaleTile<BLOCK, UNROLL>& r)
+{
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+    {
+        if (r.j[u] == (size_t)-1)
+            continue;
+        r.xy[u].x *= alpha;
+        r.xy[u].y *= alpha;
+        r.zw[u].x *= alpha;
+        vel2[2 * r.j[u]] = r.xy[u];
+        vel2[2 * r.j[u] + 1] = r.zw[u];
+    }
+}
+// tiles first, first + gridDim.x, ...; `pre`: the block's first tile has been loaded by the caller already (before a prologue
+// whose latency those loads then hide)
+template <int BLOCK, int UNROLL>
 __device__ __forceinline__ void scale_velocities_body(v2d* __restrict__ vel2, const unsigned* __restrict__ members, unsigned n,
-                                                      double alpha)
+                                                      double alpha, ScaleTile<BLOCK, UNROLL>* pre = nullptr)
 {
     constexpr unsigned TILE = BLOCK * UNROLL;
     const unsigned tiles = (n + TILE - 1) / TILE;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x)
+    unsigned t = blockIdx.x;
+    if (pre && t < tiles)
     {
-        const size_t base = (size_t)t * TILE + threadIdx.x;
-        v2d xy[UNROLL], zw[UNROLL];
-        size_t j[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            const size_t k = base + (size_t)u * BLOCK;
-            j[u] = k < n ? (members ? (size_t)members[k] : k) : (size_t)-1;
-            if (j[u] != (size_t)-1)
-            {
-                xy[u] = vel2[2 * j[u]];
-                zw[u] = vel2[2 * j[u] + 1];
-            }
-        }
+        scale_tile_store<BLOCK, UNROLL>(vel2, alpha, *pre);
+        t += gridDim.x;
+    }
+    for (; t < tiles; t += gridDim.x)
+    {
+        ScaleTile<BLOCK, UNROLL> r;
+        scale_tile_load<BLOCK, UNROLL>(vel2, members, n, t, r);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-        {
-            if (j[u] == (size_t)-1)
-                continue;
-            xy[u].x *= alpha;
-            xy[u].y *= alpha;
-            zw[u].x *= alpha;
-            vel2[2 * j[u]] = xy[u];
-            vel2[2 * j[u] + 1] = zw[u];
-        }
+        scale_tile_store<BLOCK, UNROLL>(vel2, alpha, r);
     }
 }
 
@@ -717,6 +741,11 @@ __global__ __launch_bounds__(BLOCK) void bussi_rescale_fused_kernel(v2d* __restr
                                                                     HostBussi* __restrict__ host, uint64_t sequence)
 {
     __shared__ double s_alpha;
+    // this block's first tile is asked for before the prologue, whose latency (partials, block tree, the rule) it then hides
+    ScaleTile<BLOCK, UNROLL> first;
+    const unsigned tiles = (n + BLOCK * UNROLL - 1) / (BLOCK * UNROLL);
+    if (blockIdx.x < tiles)
+        scale_tile_load<BLOCK, UNROLL>(vel2, members, n, blockIdx.x, first);
     DD tot {0.0, 0.0};
     for (unsigned p = threadIdx.x; p < G1; p += BLOCK)
         dd_merge(tot.hi, tot.lo, part[p], part[G1 + p]);
@@ -753,6 +782,6 @@ __global__ __launch_bounds__(BLOCK) void bussi_rescale_fused_kernel(v2d* __restr
     const double alpha = s_alpha;
     if (alpha == 1.0)
         return;
-    scale_velocities_body<BLOCK, UNROLL>(vel2, members, n, alpha);
+    scale_velocities_body<BLOCK, UNROLL>(vel2, members, n, alpha, &first);
 }
 } // namespace cavmd
