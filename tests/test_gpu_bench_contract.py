@@ -38,6 +38,9 @@ def test_single_gpu_line():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    # a plain single process joins no process group; its own rate is the whole job's
+    assert d["config"]["dist_backend"] is None
+    assert d["per_rank_evals_per_s"]["min"] == d["per_rank_evals_per_s"]["max"] >= d["value"] * (1 - 1e-9)
 
 
 def test_two_rank_rehearsal():
